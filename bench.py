@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: the fused SDF + central-difference-normal lattice sweep.
+
+Metric (BASELINE.json): Mvoxels/s of SDF+normal evaluation.  A step is one sweep of the whole
+(res+1)^3 lattice of the workload into buffers resident in HBM; voxels = res^3.  Default workload
+is BASELINE config 2 (single sphere, 512^3, box from the reference's own stage-A estimate).
+
+N > 1 (one process per GPU, torch.distributed over RCCL): the fixed lattice is sharded into N
+Z slabs; each rank sweeps its planes and receives the one halo plane its mesher
+needs from its upper neighbour over RCCL send/recv (the only exchange the path has).  Total work
+is fixed, so scaling is "strong".
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+BYTES_PER_POINT = 16   # 4 B SDF + 12 B normal written, nothing read
+
+WORKLOADS = {
+    # name: (fixture scene, grid level, box centre, box diameter)  -- boxes = reference stage-A goldens
+    "sphere512": ("sphere", 9, [0.0, 0.0, 0.0], 5.3515625),
+    "sphere1024": ("sphere", 10, [0.0, 0.0, 0.0], 5.3515625),
+    "design2_512": ("design2", 9, [0.0, -0.0390625, 0.0], 9.3359375),
+    "design2_1024": ("design2", 10, [0.0, -0.0390625, 0.0], 9.3359375),
+    "flat256_512": ("flat256", 9, [0.0, 0.0, 0.0], 10.0),
+}
+
+
+def cpu_baseline(scene_dir, center, diameter, res, budget_s=15.0):
+    """The oracle (own CPU restatement, kind "port") timed on this host's cores on a bounded sample
+    of the same workload: whole lattice planes around the middle of the box."""
+    from oracle import oracle as O
+    O.build()
+    osc = O.Scene.from_dir(scene_dir)
+    cores = len(os.sched_getaffinity(0))
+    n1 = res + 1
+    z = n1 // 2
+    t0 = time.perf_counter()
+    osc.eval_lattice(center, diameter, res, z, z + 1, threads=cores)
+    t1 = time.perf_counter() - t0
+    planes = max(1, min(n1 - z, int(budget_s / max(t1, 1e-4))))
+    t0 = time.perf_counter()
+    osc.eval_lattice(center, diameter, res, z, z + planes, threads=cores)
+    dt = time.perf_counter() - t0
+    pts = planes * n1 * n1
+    # voxels per lattice point, so that the unit matches `value`
+    mvox = pts * (res ** 3 / n1 ** 3) / dt / 1e6
+    return {"value": round(mvox, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+            "sample": "oracle fused SDF+normal on %d of %d lattice planes (%d points, %.1f s)" % (planes, n1, pts, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sphere512", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from designcsg_amd.evaluator import Evaluator
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                 % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    scene, grid_level, center, diameter = WORKLOADS[args.workload]
+    scene_dir = os.path.join(ROOT, "tests", "golden", "scenes", scene)
+    res = 1 << grid_level
+    n1 = res + 1
+    ev = Evaluator(local_rank)
+    status, log = ev.build_from_dir(scene_dir)
+    if status != 0:
+        sys.exit("scene build failed:\n" + log)
+
+    # Z slab of this rank: planes [lo, hi) are its own, plane hi is the halo its mesher reads;
+    # the last rank owns plane res as well.
+    lo, hi = rank * res // world, (rank + 1) * res // world
+    own_hi = hi if rank < world - 1 else n1
+    planes = hi - lo + 1
+    plane = n1 * n1
+    sdf = torch.empty(planes * plane, dtype=torch.float32, device="cuda")
+    nrm = torch.empty(planes * plane * 3, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        # own planes; the first one is what the lower neighbour needs, so it goes first
+        if world > 1 and rank > 0:
+            ev.sweep_lattice_device(center, diameter, res, lo, lo + 1, sdf.data_ptr(), nrm.data_ptr(),
+                                    stream.cuda_stream)
+            reqs = [dist.isend(sdf[:plane], rank - 1), dist.isend(nrm[:3 * plane], rank - 1)]
+            first = lo + 1
+        else:
+            reqs, first = [], lo
+        if world > 1 and rank < world - 1:
+            reqs += [dist.irecv(sdf[(hi - lo) * plane:], rank + 1), dist.irecv(nrm[(hi - lo) * plane * 3:], rank + 1)]
+        off = first - lo
+        ev.sweep_lattice_device(center, diameter, res, first, own_hi,
+                                sdf.data_ptr() + off * plane * 4, nrm.data_ptr() + off * plane * 12,
+                                stream.cuda_stream)
+        for r in reqs:
+            r.wait()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # kernel time, live: device events on the stream the sweep is launched on
+    k_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        k_ev[i][0].record(stream)
+        step()
+        k_ev[i][1].record(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = res ** 3 * args.steps / dt / 1e6
+        kernel_ms = sum(a.elapsed_time(b) for a, b in k_ev) / args.steps
+        own_points = (own_hi - lo) * plane
+        achieved = BYTES_PER_POINT * own_points / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mvoxels/s SDF+normal eval", "value": round(value, 2), "unit": "Mvoxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s scene, fused SDF+normal sweep of the %d^3 lattice (%d^3 voxels), "
+                                   "box centre %s diameter %s" % (scene, n1, res, center, diameter),
+                       "grid_level": grid_level, "parallelism": "z-slab x%d" % world,
+                       "lattice_points": n1 ** 3},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "dcsg_sweep", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": BYTES_PER_POINT * own_points},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_dir, center, diameter, res)
+        print(json.dumps(out))
+    ev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+"""Builds every native artefact of designcsg_amd for gfx950, in-tree under designcsg_amd/_build/.
+
+  dcsg_builtin.hsaco        kernels.hip with the HIP-native built-in brush bank (code object)
+  dcsg_kernels_extern.bc    kernels.hip as device bitcode, linked against a scene.cl at load time
+  libdcsg_hip.so            the C ABI (include/dcsg.h): host side + comgr JIT
+  jitcache/*.hsaco          per-scene code objects compiled ahead of time (optional warm-up)
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container; the outputs travel
+to the GPU box with the source tree.
+"""
+import ctypes
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "_build")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+ARCH = "gfx950"
+# numerics contract of kernels.hip: no contraction, IEEE divide/sqrt (hipcc default), no fast-math
+DEVICE_FLAGS = ["--offload-arch=" + ARCH, "--cuda-device-only", "-O3", "-ffp-contract=off", "-std=c++17"]
+LIB = os.path.join(OUT, "libdcsg_hip.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError("build step failed: " + cmd[0])
+
+
+def _embed_cl():
+    """scene_prelude.cl / scene_epilogue.cl -> C++ raw string literals for jit.cpp."""
+    dst = os.path.join(OUT, "embedded_cl.inc")
+    srcs = [os.path.join(CSRC, "scene_prelude.cl"), os.path.join(CSRC, "scene_epilogue.cl")]
+    if not _newer(dst, srcs):
+        return
+    with open(dst, "w") as f:
+        for name, path in zip(("kScenePrelude", "kSceneEpilogue"), srcs):
+            f.write('static const char %s[] = R"DCSG_CL(%s)DCSG_CL";\n' % (name, open(path).read()))
+
+
+def build(verbose=False, prebuild_scenes=True):
+    os.makedirs(OUT, exist_ok=True)
+    kernels = os.path.join(CSRC, "kernels.hip")
+    dev_deps = [kernels, os.path.join(CSRC, "dcsg_device_params.h")]
+
+    hsaco = os.path.join(OUT, "dcsg_builtin.hsaco")
+    if _newer(hsaco, dev_deps):
+        _run([HIPCC] + DEVICE_FLAGS + ["--no-gpu-bundle-output", "-c", kernels, "-o", hsaco])
+    bc = os.path.join(OUT, "dcsg_kernels_extern.bc")
+    if _newer(bc, dev_deps):
+        _run([HIPCC] + DEVICE_FLAGS + ["-fgpu-rdc", "-emit-llvm", "-DDCSG_EXTERN_BANK", "-c", kernels, "-o", bc])
+
+    _embed_cl()
+    host_src = [os.path.join(CSRC, f) for f in ("dcsg_api.cpp", "scene.cpp", "jit.cpp")]
+    host_deps = host_src + glob.glob(os.path.join(CSRC, "*.h*")) + \
+        [os.path.join(OUT, "embedded_cl.inc"), os.path.join(HERE, "..", "include", "dcsg.h")]
+    if _newer(LIB, host_deps):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+              "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"), "-I" + OUT, "-I" + CSRC]
+             + host_src + ["-o", LIB, "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-lamd_comgr", "-ldl",
+                           "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+    if prebuild_scenes:
+        prebuild_jit_cache(verbose)
+    return LIB
+
+
+def prebuild_jit_cache(verbose=False):
+    """Compile the fixture scenes' scene.cl into the JIT cache (no GPU needed)."""
+    lib = ctypes.CDLL(LIB)
+    lib.dcsg_jit_prebuild.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                                      ctypes.POINTER(ctypes.c_int)]
+    scenes = sorted(glob.glob(os.path.join(HERE, "..", "tests", "golden", "scenes", "*", "scene.cl")))
+    for path in scenes:
+        log = ctypes.create_string_buffer(1 << 16)
+        cached = ctypes.c_int(0)
+        rc = lib.dcsg_jit_prebuild(open(path, "rb").read(), log, len(log), ctypes.byref(cached))
+        if rc != 0:
+            raise RuntimeError("JIT of %s failed:\n%s" % (path, log.value.decode(errors="replace")))
+        if verbose:
+            print("jit", os.path.relpath(path), "cached" if cached.value else "compiled")
+
+
+if __name__ == "__main__":
+    build(verbose=True)
+    print(LIB)

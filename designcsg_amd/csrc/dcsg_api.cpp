@@ -1,0 +1,829 @@
+// dcsg_api.cpp -- C ABI of libdcsg_hip.so (include/dcsg.h): host side of the MI355X export path.
+//
+// Replaces Evaluator.{h,cpp} (OpenCL dispatch of k2), ISV.hpp (lazy block cache), the host octree
+// mesher / projection loop of cms/main/Headers/mesh.hpp, the writers of utils.hpp and the driver
+// MyFrame::OnExportInner (DesignCSG.cpp:638-790).  There is no CPU fallback: without a HIP device
+// every entry point fails with DCSG_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dcsg.h"
+#include "dcsg_device_params.h"
+#include "jit.hpp"
+#include "scene.hpp"
+
+using namespace dcsg;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct Kernels {
+    hipFunction_t sweep = nullptr, eval_points = nullptr, bbox = nullptr, classify = nullptr, scan = nullptr,
+                  emit = nullptr, project = nullptr, set_ad = nullptr;
+};
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct dcsg_ctx {
+    int device = 0;
+    int n_cu = 256;
+    size_t max_lds = 65536;
+    hipStream_t stream = nullptr;
+    hipModule_t builtin_mod = nullptr, scene_mod = nullptr;
+    Kernels kb, ks;       // built-in bank / scene module
+    Kernels* k = nullptr;  // active
+    bool scene_loaded = false, jit = false;
+    Scene scene;
+    std::vector<float> ad_host;
+    std::vector<uint8_t> tri_table;
+    DevBuf d_blob, d_ad, d_tri_table, d_pts, d_out, d_nodes[2], d_info, d_block_sums, d_small, d_tris, d_lat_sdf,
+        d_lat_nrm;
+    uint64_t n_tris = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_sweep_time = false;
+    std::string err;
+};
+
+namespace {
+
+int fail(dcsg_ctx* c, int code, const std::string& msg)
+{
+    if (c)
+        c->err = msg;
+    else
+        g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(ctx, DCSG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+int ensure(dcsg_ctx* c, DevBuf& b, size_t bytes, bool preserve = false, size_t keep_bytes = 0)
+{
+    if (bytes <= b.cap && b.p) return 0;
+    size_t want = bytes < 256 ? 256 : bytes;
+    if (preserve && b.cap) want = want > b.cap + b.cap / 2 ? want : b.cap + b.cap / 2;
+    void* np = nullptr;
+    HIPCHK(c, hipMalloc(&np, want));
+    if (b.p) {
+        if (preserve && keep_bytes) {
+            hipError_t e = hipMemcpyAsync(np, b.p, keep_bytes, hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) {
+                hipFree(np);
+                return fail(c, DCSG_ERR_HIP, std::string("device realloc copy: ") + hipGetErrorString(e));
+            }
+        }
+        HIPCHK(c, hipFree(b.p));
+    }
+    b.p = np;
+    b.cap = want;
+    return 0;
+}
+
+void release(DevBuf& b)
+{
+    if (b.p) hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
+{
+    struct {
+        const char* name;
+        hipFunction_t* f;
+    } tab[] = {{"dcsg_sweep", &k.sweep},         {"dcsg_eval_points", &k.eval_points}, {"dcsg_bbox", &k.bbox},
+               {"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan},      {"dcsg_mesh_emit", &k.emit},
+               {"dcsg_project", &k.project}};
+    for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
+    if (scene_module) HIPCHK(c, hipModuleGetFunction(&k.set_ad, mod, "dcsg_set_arbitrary_data"));
+    return 0;
+}
+
+int launch(dcsg_ctx* c, hipFunction_t f, unsigned grid, unsigned block, size_t lds, hipStream_t s, void** args)
+{
+    if (grid == 0) return 0;
+    HIPCHK(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds, s, args, nullptr));
+    return 0;
+}
+
+// ISV3D64 geometry for box{center,diameters}, res (ISV.hpp:91-109); float ops exactly as written there.
+DcsgLattice make_lattice(const float center[3], const float diam[3], int res)
+{
+    DcsgLattice L;
+    for (int k = 0; k < 3; k++) {
+        volatile float h = 0.5f * diam[k];  // v3f_scale(bb.diameters, 0.5)
+        L.base[k] = center[k] - h;          // v3f_sub(bb.center, ...)
+        L.diam[k] = diam[k];
+        L.center[k] = center[k];
+        L.half[k] = diam[k] / 2.0f;
+    }
+    L.w = (float)res;
+    L.inv_w = 1.0f / (float)res;
+    L.res = res;
+    L.w_pow2 = (res > 0 && (res & (res - 1)) == 0) ? 1 : 0;
+    return L;
+}
+
+unsigned sweep_grid(const dcsg_ctx* c, unsigned tiles)
+{
+    unsigned cap = (unsigned)c->n_cu * 32u;  // 8 resident 256-thread blocks per CU, x4 for tail balance
+    return tiles < cap ? tiles : cap;
+}
+
+int need_scene(dcsg_ctx* c)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    if (!c->scene_loaded) return fail(c, DCSG_ERR_NO_SCENE, "no scene loaded (\"Cannot Export Yet.\")");
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, DCSG_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int eval_points_device(dcsg_ctx* c, const float* d_xyz, size_t n, int mode, float* d_out, hipStream_t s)
+{
+    const size_t chunk = 256u * 256u * 256u;  // MAX_EVAL_POINTS, Evaluator.h:16
+    const void* blob = c->d_blob.p;
+    int nv = c->scene.blob_vec4();
+    for (size_t off = 0; off < n; off += chunk) {
+        unsigned cnt = (unsigned)((n - off) < chunk ? (n - off) : chunk);
+        const float* in = d_xyz + off * 3;
+        float* out = d_out + off * (mode == 0 ? 1 : 3);
+        unsigned tiles = (cnt + DCSG_BLOCK - 1) / DCSG_BLOCK;
+        void* args[] = {(void*)&blob, &nv, (void*)&in, &cnt, &mode, (void*)&out};
+        int r = launch(c, c->k->eval_points, sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), s, args);
+        if (r) return r;
+    }
+    return 0;
+}
+
+int eval_points_host(dcsg_ctx* c, const float* xyz, size_t n, int mode, float* out)
+{
+    int r = need_scene(c);
+    if (r) return r;
+    if (n == 0) return 0;
+    if (!xyz || !out) return fail(c, DCSG_ERR_INVALID, "NULL point / output buffer");
+    const size_t chunk = 256u * 256u * 256u;
+    const size_t per = mode == 0 ? 1 : 3;
+    for (size_t off = 0; off < n; off += chunk) {
+        size_t cnt = (n - off) < chunk ? (n - off) : chunk;
+        if ((r = ensure(c, c->d_pts, cnt * 3 * sizeof(float)))) return r;
+        if ((r = ensure(c, c->d_out, cnt * per * sizeof(float)))) return r;
+        HIPCHK(c, hipMemcpyAsync(c->d_pts.p, xyz + off * 3, cnt * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        if ((r = eval_points_device(c, (const float*)c->d_pts.p, cnt, mode, (float*)c->d_out.p, c->stream))) return r;
+        HIPCHK(c, hipMemcpyAsync(out + off * per, c->d_out.p, cnt * per * sizeof(float), hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int res, int z0, int z1, float* d_sdf,
+                 float* d_nrm, hipStream_t s, bool time_it)
+{
+    if (res < 1 || z0 < 0 || z1 > res + 1 || z0 > z1) return fail(c, DCSG_ERR_INVALID, "bad lattice range");
+    if (!d_sdf && !d_nrm) return 0;
+    const uint64_t n1 = (uint64_t)res + 1;
+    const uint64_t total = (uint64_t)(z1 - z0) * n1 * n1;
+    if (total >= 0xffffff00ull)
+        return fail(c, DCSG_ERR_INVALID, "lattice slab has >= 2^32 points; sweep it in smaller Z ranges");
+    DcsgLattice L = make_lattice(center, diam, res);
+    const void* blob = c->d_blob.p;
+    int nv = c->scene.blob_vec4();
+    if (time_it) HIPCHK(c, hipEventRecord(c->ev0, s));
+    const uint64_t chunk = 1ull << 30;
+    for (uint64_t first64 = 0; first64 < total; first64 += chunk) {
+        unsigned first = (unsigned)first64;
+        unsigned cnt = (unsigned)((total - first64) < chunk ? (total - first64) : chunk);
+        unsigned tiles = (cnt + DCSG_BLOCK - 1) / DCSG_BLOCK;
+        void* args[] = {(void*)&blob, &nv, &L, &z0, &first, &cnt, (void*)&d_sdf, (void*)&d_nrm};
+        int r = launch(c, c->k->sweep, sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), s, args);
+        if (r) return r;
+    }
+    if (time_it) {
+        HIPCHK(c, hipEventRecord(c->ev1, s));
+        c->have_sweep_time = true;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ======================================================================================
+extern "C" {
+
+const char* dcsg_last_error(const dcsg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int dcsg_create(dcsg_ctx** out, int device_id)
+{
+    if (!out) return fail(nullptr, DCSG_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, DCSG_ERR_NO_DEVICE,
+                    std::string("no HIP device visible (") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
+                        "): libdcsg_hip has no CPU fallback");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, DCSG_ERR_INVALID, "device_id out of range");
+    dcsg_ctx* c = new dcsg_ctx();
+    c->device = device_id;
+    auto bail = [&](int code) {
+        g_create_error = c->err;
+        dcsg_destroy(c);
+        return code;
+    };
+#define CK(expr)                                                                                        \
+    do {                                                                                                \
+        hipError_t e2 = (expr);                                                                         \
+        if (e2 != hipSuccess) {                                                                         \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(e2);                                 \
+            return bail(DCSG_ERR_HIP);                                                                  \
+        }                                                                                               \
+    } while (0)
+    CK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, device_id));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipEventCreate(&c->ev0));
+    CK(hipEventCreate(&c->ev1));
+    std::string dir = library_dir(), bytes;
+    if (!read_file(dir + "/dcsg_builtin.hsaco", bytes)) {
+        c->err = "cannot read " + dir + "/dcsg_builtin.hsaco (run __graft_entry__.build())";
+        return bail(DCSG_ERR_IO);
+    }
+    CK(hipModuleLoadData(&c->builtin_mod, bytes.data()));
+    if (load_kernels(c, c->builtin_mod, c->kb, false)) return bail(DCSG_ERR_HIP);
+    std::string table_txt;
+    if (!read_file(dir + "/../data/lookupTable.txt", table_txt)) {
+        c->err = "cannot read packaged lookupTable.txt next to the library";
+        return bail(DCSG_ERR_IO);
+    }
+    *out = c;  // dcsg_set_lookup_table reports through ctx
+    int r = dcsg_set_lookup_table(c, table_txt.c_str());
+    if (r) {
+        *out = nullptr;
+        return bail(r);
+    }
+    c->ad_host.assign(DCSG_ARBITRARY_DATA_POINTS, 0.0f);
+    return 0;
+#undef CK
+}
+
+void dcsg_destroy(dcsg_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->d_blob,  &c->d_ad,         &c->d_tri_table, &c->d_pts,  &c->d_out,     &c->d_nodes[0],
+                      &c->d_nodes[1], &c->d_info,    &c->d_block_sums, &c->d_small, &c->d_tris, &c->d_lat_sdf,
+                      &c->d_lat_nrm};
+    for (auto* b : bufs) release(*b);
+    if (c->scene_mod) hipModuleUnload(c->scene_mod);
+    if (c->builtin_mod) hipModuleUnload(c->builtin_mod);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dcsg_set_lookup_table(dcsg_ctx* c, const char* txt)
+{
+    if (!c || !txt) return fail(c, DCSG_ERR_INVALID, "NULL argument");
+    std::vector<uint8_t> t;
+    int total = 0;
+    std::string err;
+    if (!parse_lookup_table(txt, t, total, err)) return fail(c, DCSG_ERR_INVALID, err);
+    HIPCHK(c, hipSetDevice(c->device));
+    int r = ensure(c, c->d_tri_table, t.size());
+    if (r) return r;
+    HIPCHK(c, hipMemcpy(c->d_tri_table.p, t.data(), t.size(), hipMemcpyHostToDevice));
+    c->tri_table = t;
+    return 0;
+}
+
+int dcsg_set_arbitrary_data(dcsg_ctx* c, const float* data, size_t items)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    if (items > DCSG_ARBITRARY_DATA_POINTS) return fail(c, DCSG_ERR_INVALID, "more than 131072 arbitrary data items");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (data && items) memcpy(c->ad_host.data(), data, items * sizeof(float));  // Evaluator.cpp:214
+    int r = ensure(c, c->d_ad, DCSG_ARBITRARY_DATA_POINTS * sizeof(float));
+    if (r) return r;
+    HIPCHK(c, hipMemcpy(c->d_ad.p, c->ad_host.data(), DCSG_ARBITRARY_DATA_POINTS * sizeof(float),
+                        hipMemcpyHostToDevice));  // uploads all 131072, Evaluator.cpp:215-223
+    if (c->scene_loaded && c->jit) {
+        void* ad = c->d_ad.p;
+        void* args[] = {&ad};
+        if ((r = launch(c, c->ks.set_ad, 1, 64, 0, c->stream, args))) return r;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, const char* scene_cl,
+                    const float* ad, size_t n_ad)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->scene_loaded = false;
+    Scene s;
+    std::string err;
+    if (!parse_scene(scene_txt, bp_txt, s, err)) return fail(c, DCSG_ERR_INVALID, err);
+    bool builtin;
+    std::string cl = scene_cl ? scene_cl : "";
+    if (!scene_cl) {
+        if (s.max_brush_id > 4)
+            return fail(c, DCSG_ERR_INVALID,
+                        "scene uses brush id " + std::to_string(s.max_brush_id) + " but no scene.cl was given");
+        builtin = true;
+    } else {
+        builtin = s.max_brush_id <= 4 && scene_cl_is_builtin_only(cl);
+    }
+    if (s.lds_bytes() > 160 * 1024)
+        return fail(c, DCSG_ERR_INVALID, "scene tables need " + std::to_string(s.lds_bytes()) + " B of LDS (> 160 KiB)");
+    if (builtin) {
+        build_blob(s, true);
+        c->k = &c->kb;
+        c->jit = false;
+    } else {
+        std::string hsaco, log;
+        if (!jit_scene_module(cl, hsaco, log, nullptr))
+            return fail(c, DCSG_ERR_BUILD, "Error when building evaluation program:\n" + log);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->scene_mod) {
+            HIPCHK(c, hipModuleUnload(c->scene_mod));
+            c->scene_mod = nullptr;
+        }
+        HIPCHK(c, hipModuleLoadData(&c->scene_mod, hsaco.data()));
+        int r = load_kernels(c, c->scene_mod, c->ks, true);
+        if (r) return r;
+        build_blob(s, scene_cl_null_brush_is_const(cl));
+        c->k = &c->ks;
+        c->jit = true;
+    }
+    int r = ensure(c, c->d_blob, s.blob.size() * 4);
+    if (r) return r;
+    HIPCHK(c, hipMemcpy(c->d_blob.p, s.blob.data(), s.blob.size() * 4, hipMemcpyHostToDevice));
+    c->scene = std::move(s);
+    c->scene_loaded = true;
+    c->n_tris = 0;
+    std::fill(c->ad_host.begin(), c->ad_host.end(), 0.0f);
+    return dcsg_set_arbitrary_data(c, ad, ad ? n_ad : 0);
+}
+
+int dcsg_scene_info(const dcsg_ctx* c, int* n_objects, int* n_steps, int* n_slots, int* jit_compiled)
+{
+    if (!c || !c->scene_loaded) return DCSG_ERR_NO_SCENE;
+    if (n_objects) *n_objects = c->scene.n_objects;
+    if (n_steps) *n_steps = c->scene.n_steps;
+    if (n_slots) *n_slots = c->scene.n_slots;
+    if (jit_compiled) *jit_compiled = c->jit ? 1 : 0;
+    return 0;
+}
+
+int dcsg_eval_sdf(dcsg_ctx* c, const float* xyz, size_t n, float* out) { return eval_points_host(c, xyz, n, 0, out); }
+int dcsg_eval_normal(dcsg_ctx* c, const float* xyz, size_t n, float* out) { return eval_points_host(c, xyz, n, 1, out); }
+
+int dcsg_eval_sdf_device(dcsg_ctx* c, const float* d_xyz, size_t n, float* d_out, void* stream)
+{
+    int r = need_scene(c);
+    return r ? r : eval_points_device(c, d_xyz, n, 0, d_out, (hipStream_t)stream);
+}
+int dcsg_eval_normal_device(dcsg_ctx* c, const float* d_xyz, size_t n, float* d_out, void* stream)
+{
+    int r = need_scene(c);
+    return r ? r : eval_points_device(c, d_xyz, n, 1, d_out, (hipStream_t)stream);
+}
+
+int dcsg_sweep_lattice_device(dcsg_ctx* c, const float center[3], const float diameters[3], int res, int z0, int z1,
+                              float* d_sdf, float* d_normals, void* stream)
+{
+    int r = need_scene(c);
+    return r ? r : sweep_device(c, center, diameters, res, z0, z1, d_sdf, d_normals, (hipStream_t)stream, true);
+}
+
+int dcsg_last_sweep_ms(dcsg_ctx* c, double* ms)
+{
+    if (!c || !ms) return DCSG_ERR_INVALID;
+    if (!c->have_sweep_time) return fail(c, DCSG_ERR_INVALID, "no sweep has been timed yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float t = 0;
+    HIPCHK(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
+    *ms = t;
+    return 0;
+}
+
+int dcsg_eval_lattice(dcsg_ctx* c, const float center[3], const float diameters[3], int res, int z0, int z1,
+                      float* sdf, float* normals)
+{
+    int r = need_scene(c);
+    if (r) return r;
+    if (res < 1 || z0 < 0 || z1 > res + 1 || z0 > z1) return fail(c, DCSG_ERR_INVALID, "bad lattice range");
+    size_t n = (size_t)(z1 - z0) * (size_t)(res + 1) * (size_t)(res + 1);
+    if (n == 0 || (!sdf && !normals)) return 0;
+    if (sdf && (r = ensure(c, c->d_lat_sdf, n * sizeof(float)))) return r;
+    if (normals && (r = ensure(c, c->d_lat_nrm, n * 3 * sizeof(float)))) return r;
+    if ((r = sweep_device(c, center, diameters, res, z0, z1, sdf ? (float*)c->d_lat_sdf.p : nullptr,
+                          normals ? (float*)c->d_lat_nrm.p : nullptr, c->stream, true)))
+        return r;
+    if (sdf) HIPCHK(c, hipMemcpyAsync(sdf, c->d_lat_sdf.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (normals)
+        HIPCHK(c, hipMemcpyAsync(normals, c->d_lat_nrm.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Stage A, DesignCSG.cpp:668-712
+int dcsg_estimate_bounding_box(dcsg_ctx* c, float bb_half, float center[3], float* diameter, uint64_t* interior)
+{
+    int r = need_scene(c);
+    if (r) return r;
+    const int R = 256;
+    volatile float cd = (float)bb_half / R;  // cube_diameter
+    volatile float half_neg = -cd / 2;       // v3f(-cube_diameter / 2)
+    double bb_eps = (double)((float)bb_half / R) * 1.0;  // BB_EPSILON
+    if ((r = ensure(c, c->d_small, 4096))) return r;
+    int seed[12] = {1 << 20, 1 << 20, 1 << 20, -(1 << 20), -(1 << 20), -(1 << 20), 0, 0, 0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(c->d_small.p, seed, sizeof(seed), hipMemcpyHostToDevice, c->stream));
+    const void* blob = c->d_blob.p;
+    int nv = c->scene.blob_vec4();
+    float cdv = cd, hnv = half_neg;
+    int* res_ptr = (int*)c->d_small.p;
+    void* args[] = {(void*)&blob, &nv, &cdv, &hnv, &bb_eps, (void*)&res_ptr};
+    if ((r = launch(c, c->k->bbox, (unsigned)c->n_cu * 16u, DCSG_BLOCK, c->scene.lds_bytes(), c->stream, args)))
+        return r;
+    int out[12];
+    HIPCHK(c, hipMemcpyAsync(out, c->d_small.p, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t cnt;
+    memcpy(&cnt, &out[8], 8);
+    float mn[3] = {0.0f, 0.0f, 0.0f}, mx[3] = {0.0f, 0.0f, 0.0f};  // initialised to 0.0, :688-693
+    if (cnt) {
+        for (int k = 0; k < 3; k++) {
+            volatile float a = cd * (float)out[k];      // v3f_scale(v3f(ix,iy,iz), cube_diameter)
+            volatile float b = cd * (float)out[3 + k];
+            float pmin = half_neg + a, pmax = half_neg + b;  // v3f_add
+            if (pmin < mn[k]) mn[k] = pmin;
+            if (pmax > mx[k]) mx[k] = pmax;
+        }
+    }
+    float d[3];
+    for (int k = 0; k < 3; k++) {
+        volatile float sum = mn[k] + mx[k];
+        center[k] = (float)((double)sum * 0.5);  // :703
+        d[k] = mx[k] - mn[k];                    // :704
+    }
+    float inner = d[1] > d[2] ? d[1] : d[2];  // T_max, :706
+    *diameter = d[0] > inner ? d[0] : inner;
+    if (interior) *interior = cnt;
+    return 0;
+}
+
+int dcsg_parse_export_config(const char* txt, dcsg_export_config* out)
+{
+    std::string err;
+    if (!out) return DCSG_ERR_INVALID;
+    if (!parse_export_config(txt, *out, err)) {
+        g_create_error = err;
+        return DCSG_ERR_INVALID;
+    }
+    return 0;
+}
+
+// Mesh::getSurface, mesh.hpp:82-389, level-synchronous on the device.
+int dcsg_mesh_lattice_device(dcsg_ctx* c, const float center[3], float diameter, const dcsg_export_config* cfg,
+                             const float* d_sdf, const float* d_normals, int z_lo, int z_hi, int z_own_lo,
+                             int z_own_hi, uint64_t* n_triangles, dcsg_mesh_stats* stats, void* stream_v)
+{
+    int r = need_scene(c);
+    if (r) return r;
+    if (!cfg || !center) return fail(c, DCSG_ERR_INVALID, "NULL argument");
+    if (cfg->grid_level < 1 || cfg->grid_level > 12 || cfg->max_level < 2 || cfg->max_level > cfg->grid_level ||
+        cfg->min_level > cfg->max_level || cfg->max_level >= DCSG_MAX_LEVELS)
+        return fail(c, DCSG_ERR_INVALID, "export levels must satisfy 2 <= max, min <= max <= grid <= 12");
+    if (c->tri_table.empty()) return fail(c, DCSG_ERR_INVALID, "no lookup table");
+    hipStream_t s = (hipStream_t)stream_v;
+    const int res = 1 << cfg->grid_level;
+    if (!d_sdf) z_lo = 1, z_hi = 0;  // nothing resident: every sample is evaluated on demand
+    float diam[3] = {diameter, diameter, diameter};
+
+    DcsgMeshParams P;
+    memset(&P, 0, sizeof(P));
+    P.lat = make_lattice(center, diam, res);
+    P.min_level = cfg->min_level;
+    P.max_level = cfg->max_level;
+    P.grid_level = cfg->grid_level;
+    P.q_star = angle_threshold_to_q_star(cfg->complex_surface_threshold);
+    P.z_lo = z_lo;
+    P.z_hi = z_hi;
+    P.has_normals = d_normals ? 1 : 0;
+    P.z_own_lo = z_own_lo;
+    P.z_own_hi = z_own_hi;
+
+    // mesh.hpp:110-125: levels 0 and 1 are subdivided unconditionally; the 64 level-2 nodes start the
+    // traversal.  Child centre = center + ((hd*sign)*0.5f), child hd = 0.5f*hd (octree.hpp:24-32).
+    static const float SG[8][3] = {{-1, -1, 1}, {1, -1, 1}, {1, -1, -1}, {-1, -1, -1},
+                                   {-1, 1, 1},  {1, 1, 1},  {1, 1, -1},  {-1, 1, -1}};
+    float hd0[3], hd1[3], hd2[3];
+    for (int k = 0; k < 3; k++) {
+        hd0[k] = diam[k] / 2.0f;  // DesignCSG.cpp:718
+        hd1[k] = 0.5f * hd0[k];
+        hd2[k] = 0.5f * hd1[k];
+    }
+    std::vector<float> roots;
+    roots.reserve(64 * 3);
+    for (int a = 0; a < 8; a++) {
+        float c1[3];
+        for (int k = 0; k < 3; k++) {
+            volatile float t = hd0[k] * SG[a][k];
+            volatile float u = 0.5f * t;
+            c1[k] = center[k] + u;
+        }
+        for (int b = 0; b < 8; b++)
+            for (int k = 0; k < 3; k++) {
+                volatile float t = hd1[k] * SG[b][k];
+                volatile float u = 0.5f * t;
+                roots.push_back(c1[k] + u);
+            }
+    }
+    unsigned n_nodes = 64;
+    if ((r = ensure(c, c->d_nodes[0], (size_t)n_nodes * 3 * sizeof(float)))) return r;
+    HIPCHK(c, hipMemcpyAsync(c->d_nodes[0].p, roots.data(), roots.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    // d_small: [0..1] totals (u32), level stats at byte 256: [level][4] u64
+    if ((r = ensure(c, c->d_small, 4096))) return r;
+    HIPCHK(c, hipMemsetAsync(c->d_small.p, 0, 4096, s));
+    unsigned* d_totals = (unsigned*)c->d_small.p;
+    unsigned long long* d_lstats = (unsigned long long*)((char*)c->d_small.p + 256);
+
+    dcsg_mesh_stats st;
+    memset(&st, 0, sizeof(st));
+    uint64_t n_tris = 0;
+    int cur = 0;
+    float hd[3] = {hd2[0], hd2[1], hd2[2]};
+    const void* blob = c->d_blob.p;
+    int nv = c->scene.blob_vec4();
+    const unsigned char* d_table = (const unsigned char*)c->d_tri_table.p;
+    for (int level = 2; level <= cfg->max_level && n_nodes > 0; level++) {
+        P.level = level;
+        for (int k = 0; k < 3; k++) P.hd[k] = hd[k];
+        unsigned n_blocks = (n_nodes + DCSG_BLOCK - 1) / DCSG_BLOCK;
+        if ((r = ensure(c, c->d_info, (size_t)n_nodes * sizeof(unsigned short)))) return r;
+        if ((r = ensure(c, c->d_block_sums, (size_t)n_blocks * 2 * sizeof(unsigned)))) return r;
+        const float* d_nodes = (const float*)c->d_nodes[cur].p;
+        unsigned short* d_info = (unsigned short*)c->d_info.p;
+        unsigned* d_bs = (unsigned*)c->d_block_sums.p;
+        unsigned long long* d_ls = d_lstats + 4 * level;
+        {
+            void* args[] = {(void*)&blob, &nv, &P, (void*)&d_nodes, &n_nodes, (void*)&d_sdf, (void*)&d_normals,
+                            (void*)&d_table, (void*)&d_info, (void*)&d_bs, (void*)&d_ls};
+            if ((r = launch(c, c->k->classify, n_blocks, DCSG_BLOCK, c->scene.lds_bytes(), s, args))) return r;
+        }
+        {
+            void* args[] = {(void*)&d_bs, &n_blocks, (void*)&d_totals};
+            if ((r = launch(c, c->k->scan, 1, 1024, 0, s, args))) return r;
+        }
+        unsigned totals[2];
+        HIPCHK(c, hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        unsigned n_children = totals[0], n_new_tris = totals[1];
+        if ((r = ensure(c, c->d_nodes[cur ^ 1], (size_t)(n_children ? n_children : 1) * 3 * sizeof(float)))) return r;
+        if ((r = ensure(c, c->d_tris, (size_t)(n_tris + n_new_tris + 1) * 9 * sizeof(float), true,
+                        (size_t)n_tris * 9 * sizeof(float))))
+            return r;
+        {
+            float* d_next = (float*)c->d_nodes[cur ^ 1].p;
+            float* d_tris = (float*)c->d_tris.p;
+            unsigned long long base = n_tris;
+            void* args[] = {&P, (void*)&d_nodes, &n_nodes, (void*)&d_info, (void*)&d_bs, (void*)&d_table,
+                            (void*)&d_next, (void*)&d_tris, &base};
+            if ((r = launch(c, c->k->emit, n_blocks, DCSG_BLOCK, 0, s, args))) return r;
+        }
+        st.triangles[level] = n_new_tris;
+        n_tris += n_new_tris;
+        n_nodes = n_children;
+        cur ^= 1;
+        for (int k = 0; k < 3; k++) hd[k] = 0.5f * hd[k];
+    }
+    unsigned long long ls[DCSG_MAX_LEVELS * 4];
+    HIPCHK(c, hipMemcpyAsync(ls, d_lstats, sizeof(ls), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int l = 0; l < DCSG_MAX_LEVELS; l++) {
+        st.culled[l] = ls[4 * l];
+        st.subdivided[l] = ls[4 * l + 1];
+        st.leaves[l] = ls[4 * l + 2];
+        st.triangles[l] = ls[4 * l + 3];
+        st.nodes[l] = st.culled[l] + st.subdivided[l] + st.leaves[l];
+    }
+    c->n_tris = n_tris;
+    if (n_triangles) *n_triangles = n_tris;
+    if (stats) *stats = st;
+    return 0;
+}
+
+int dcsg_project_vertices_device(dcsg_ctx* c, float* d_xyz, size_t n_vertices, int steps, void* stream)
+{
+    int r = need_scene(c);
+    if (r) return r;
+    if (steps <= 0 || n_vertices == 0) return 0;
+    if (n_vertices > 0xffffff00ull) return fail(c, DCSG_ERR_INVALID, "too many vertices for one launch");
+    const void* blob = c->d_blob.p;
+    int nv = c->scene.blob_vec4();
+    unsigned n = (unsigned)n_vertices;
+    unsigned tiles = (n + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    void* args[] = {(void*)&blob, &nv, (void*)&d_xyz, &n, &steps};
+    return launch(c, c->k->project, sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), (hipStream_t)stream, args);
+}
+
+int dcsg_project_triangles(dcsg_ctx* c, int steps, void* stream)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    return dcsg_project_vertices_device(c, (float*)c->d_tris.p, (size_t)c->n_tris * 3, steps, stream);
+}
+
+int dcsg_triangles_device(dcsg_ctx* c, const float** d_triangles, uint64_t* n)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    if (d_triangles) *d_triangles = (const float*)c->d_tris.p;
+    if (n) *n = c->n_tris;
+    return 0;
+}
+
+int dcsg_download_triangles(dcsg_ctx* c, float* out, uint64_t max_triangles)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    if (max_triangles < c->n_tris) return fail(c, DCSG_ERR_INVALID, "output buffer too small");
+    if (!c->n_tris) return 0;
+    if (!out) return fail(c, DCSG_ERR_INVALID, "NULL output buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->d_tris.p, (size_t)c->n_tris * 9 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// writeTrianglesToSTL, utils.hpp:41-103: 80 zero bytes, u32 count, per triangle a zero normal, then
+// A, B, C each written as (x, z, y), then u16 0.  Little-endian host assumed (x86-64).
+int dcsg_write_stl(const char* path, const float* tris, uint64_t n)
+{
+    if (!path || (n && !tris)) return DCSG_ERR_INVALID;
+    size_t bytes = 84 + (size_t)n * 50;
+    std::vector<unsigned char> buf(bytes, 0);
+    uint32_t n32 = (uint32_t)n;
+    memcpy(&buf[80], &n32, 4);
+    unsigned char* o = &buf[84];
+    for (uint64_t t = 0; t < n; t++, o += 50) {
+        const float* v = tris + t * 9;
+        float rec[9] = {v[0], v[2], v[1], v[3], v[5], v[4], v[6], v[8], v[7]};
+        memcpy(o + 12, rec, 36);
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) return DCSG_ERR_IO;
+    size_t w = fwrite(buf.data(), 1, bytes, f);
+    int ok = fclose(f) == 0 && w == bytes;
+    return ok ? 0 : DCSG_ERR_IO;
+}
+
+// writeTrianglesToPLY, utils.hpp:106-154 via happly.h:1998-2039 (header), 1538-1570 (double x,y,z),
+// 1640-1670 (uchar count + uint indices): un-indexed, vertices as doubles, faces (3i,3i+1,3i+2).
+int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
+{
+    if (!path || (n && !tris)) return DCSG_ERR_INVALID;
+    char header[512];
+    int hl = snprintf(header, sizeof(header),
+                      "ply\nformat binary_little_endian 1.0\n"
+                      "comment Written with hapPLY (https://github.com/nmwsharp/happly)\n"
+                      "element vertex %llu\nproperty double x\nproperty double y\nproperty double z\n"
+                      "element face %llu\nproperty list uchar uint vertex_indices\nend_header\n",
+                      (unsigned long long)(n * 3), (unsigned long long)n);
+    size_t bytes = (size_t)hl + (size_t)n * (72 + 13);
+    std::vector<unsigned char> buf(bytes);
+    memcpy(buf.data(), header, hl);
+    double* d = (double*)(buf.data() + hl);  // unaligned stores are fine on x86-64; use memcpy to be strict
+    unsigned char* o = buf.data() + hl;
+    for (uint64_t i = 0; i < n * 9; i++, o += 8) {
+        double v = (double)tris[i];
+        memcpy(o, &v, 8);
+    }
+    (void)d;
+    for (uint64_t t = 0; t < n; t++, o += 13) {
+        o[0] = 3;
+        uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
+        memcpy(o + 1, idx, 12);
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) return DCSG_ERR_IO;
+    size_t w = fwrite(buf.data(), 1, bytes, f);
+    int ok = fclose(f) == 0 && w == bytes;
+    return ok ? 0 : DCSG_ERR_IO;
+}
+
+// MyFrame::OnExportInner, DesignCSG.cpp:638-790
+int dcsg_export(dcsg_ctx* c, const char* cfg_txt, const char* stl_path, const char* ply_path, unsigned flags,
+                dcsg_export_stats* stats)
+{
+    int r = need_scene(c);
+    if (r) return r;
+    dcsg_export_config cfg;
+    std::string err;
+    if (!parse_export_config(cfg_txt, cfg, err)) return fail(c, DCSG_ERR_INVALID, err);
+    dcsg_export_stats st;
+    memset(&st, 0, sizeof(st));
+    double t_start = now_s(), t0 = t_start;
+
+    // stage A
+    float diameter = 0;
+    if ((r = dcsg_estimate_bounding_box(c, cfg.bounding_box_half_diameter, st.box_center, &diameter,
+                                        &st.interior_points)))
+        return r;
+    st.box_diameter = diameter;
+    st.t_bbox = now_s() - t0;
+    if (!(diameter > 0)) return fail(c, DCSG_ERR_INVALID, "bounding-box estimate is empty");
+
+    // dense lattice: every sample the reference's ISV caches would ever hold, evaluated once
+    t0 = now_s();
+    if (cfg.grid_level < 1 || cfg.grid_level > 12) return fail(c, DCSG_ERR_INVALID, "gridLevel out of range");
+    const int res = 1 << cfg.grid_level;
+    const size_t n1 = (size_t)res + 1, n_pts = n1 * n1 * n1;
+    st.lattice_points = n_pts;
+    const bool dense_normals = (flags & DCSG_EXPORT_DENSE_NORMALS) != 0;
+    if ((r = ensure(c, c->d_lat_sdf, n_pts * sizeof(float)))) return r;
+    if (dense_normals && (r = ensure(c, c->d_lat_nrm, n_pts * 3 * sizeof(float)))) return r;
+    float diam3[3] = {diameter, diameter, diameter};
+    // one launch covers < 2^32 points; sweep in Z ranges when the lattice is larger
+    const int planes_per = (int)(0xf0000000ull / (n1 * n1)) > 0 ? (int)(0xf0000000ull / (n1 * n1)) : 1;
+    double sweep_ms = 0;
+    for (int z0 = 0; z0 < (int)n1; z0 += planes_per) {
+        int z1 = z0 + planes_per < (int)n1 ? z0 + planes_per : (int)n1;
+        float* sd = (float*)c->d_lat_sdf.p + (size_t)z0 * n1 * n1;
+        float* nr = dense_normals ? (float*)c->d_lat_nrm.p + (size_t)z0 * n1 * n1 * 3 : nullptr;
+        if ((r = sweep_device(c, st.box_center, diam3, res, z0, z1, sd, nr, c->stream, true))) return r;
+        double ms = 0;
+        if ((r = dcsg_last_sweep_ms(c, &ms))) return r;
+        sweep_ms += ms;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    st.sweep_kernel_ms = sweep_ms;
+    st.t_sweep = now_s() - t0;
+
+    // mesher (retopologize = identity: the reference's is undefined behaviour)
+    t0 = now_s();
+    uint64_t n_tris = 0;
+    if ((r = dcsg_mesh_lattice_device(c, st.box_center, diameter, &cfg, (const float*)c->d_lat_sdf.p,
+                                      dense_normals ? (const float*)c->d_lat_nrm.p : nullptr, 0, res, 0, res, &n_tris,
+                                      &st.mesh, c->stream)))
+        return r;
+    st.triangles = n_tris;
+    st.t_mesh = now_s() - t0;
+
+    t0 = now_s();
+    if ((r = dcsg_project_triangles(c, cfg.gradient_descent_steps, c->stream))) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    st.t_project = now_s() - t0;
+
+    if (stl_path || ply_path) {
+        t0 = now_s();
+        std::vector<float> host((size_t)n_tris * 9 + 1);
+        if ((r = dcsg_download_triangles(c, host.data(), n_tris))) return r;
+        st.t_download = now_s() - t0;
+        if (stl_path) {
+            t0 = now_s();
+            if ((r = dcsg_write_stl(stl_path, host.data(), n_tris))) return fail(c, r, "cannot write STL");
+            st.t_write_stl = now_s() - t0;
+        }
+        if (ply_path) {
+            t0 = now_s();
+            if ((r = dcsg_write_ply(ply_path, host.data(), n_tris))) return fail(c, r, "cannot write PLY");
+            st.t_write_ply = now_s() - t0;
+        }
+    }
+    st.t_total = now_s() - t_start;
+    if (stats) *stats = st;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,32 @@
+// dcsg_device_params.h -- kernel parameter blocks shared by kernels.hip and the host side.
+// Plain C layout; passed by value through hipModuleLaunchKernel.
+#ifndef DCSG_DEVICE_PARAMS_H
+#define DCSG_DEVICE_PARAMS_H
+
+#define DCSG_BLOCK 256
+#define DCSG_WAVE 64
+#define DCSG_MAX_SLOTS 64  /* STACK_MEMORY_PER_PIXEL, Evaluator.cpp:7 */
+
+struct DcsgLattice {  // ISV3D64 geometry, ISV.hpp:91-109
+    float base[3];    // center - 0.5f*diameters   (ISV.hpp:104)
+    float diam[3];    // bb.diameters
+    float center[3];  // bb.center
+    float half[3];    // bb.diameters / 2.0f       (ISV.hpp:92)
+    float w;          // (float)res
+    float inv_w;      // 1/w, exact when res is a power of two
+    int res;          // lattice has (res+1)^3 points
+    int w_pow2;       // 1 -> x/w == x*inv_w bit-for-bit
+};
+
+struct DcsgMeshParams {
+    DcsgLattice lat;
+    float hd[3];       // node half diameter at this level
+    int level, min_level, max_level, grid_level;
+    float q_star;      // angle test: acos(q) > threshold  <=>  -1 <= q <= q_star
+    int z_lo, z_hi;    // lattice planes resident in sdf[] / nrm[]: z_lo..z_hi inclusive
+    int has_normals;   // nrm[] resident; otherwise normals are evaluated on demand
+    int z_own_lo, z_own_hi;  // Z-slab owned by this rank: nodes that do not intersect it are dropped,
+                             // leaves emit triangles only where their lowest plane is in [z_own_lo, z_own_hi)
+};
+
+#endif

@@ -1,0 +1,219 @@
+// jit.cpp -- builds the per-scene gfx950 code object.
+//
+// Replaces Evaluator::build (Evaluator.cpp:45-112: clBuildProgram of k2.cl + scene.cl with
+// "-D STACK_MEMORY_PER_PIXEL=64 -w", Utils.cpp:78-81).  The user's brush bodies are OpenCL C text
+// inside the scene format, so that text alone goes through the OpenCL C *language front-end*
+// (no OpenCL runtime) to gfx950 bitcode; it is linked with the hand-written HIP kernels
+// (kernels.hip built to bitcode with DCSG_EXTERN_BANK) and lowered to one code object:
+//   comgr: COMPILE_SOURCE_WITH_DEVICE_LIBS_TO_BC -> LINK_BC_TO_BC -> CODEGEN_BC_TO_RELOCATABLE
+//          -> LINK_RELOCATABLE_TO_EXECUTABLE
+// all in-process (libamd_comgr), so nothing is exec'ed from a process that owns the GPU.
+// Code objects are cached on disk keyed by a hash of every input.
+#include "jit.hpp"
+
+#include <amd_comgr/amd_comgr.h>
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "scene.hpp"
+
+namespace dcsg {
+
+#include "embedded_cl.inc"  // kScenePrelude / kSceneEpilogue, generated from the .cl files by build.py
+
+static const char* kIsa = "amdgcn-amd-amdhsa--gfx950";
+
+std::string library_dir()
+{
+    Dl_info info;
+    if (dladdr((void*)&library_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s = p.rfind('/');
+        return s == std::string::npos ? "." : p.substr(0, s);
+    }
+    return ".";
+}
+
+bool read_file(const std::string& path, std::string& out)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    out = ss.str();
+    return true;
+}
+
+static bool write_file_atomic(const std::string& path, const std::string& data)
+{
+    std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        if (!f) return false;
+        f.write(data.data(), (std::streamsize)data.size());
+        if (!f) return false;
+    }
+    return rename(tmp.c_str(), path.c_str()) == 0;
+}
+
+static std::string cache_dir()
+{
+    const char* env = getenv("DCSG_JIT_CACHE");
+    std::string d = env ? env : library_dir() + "/jitcache";
+    mkdir(d.c_str(), 0777);
+    if (access(d.c_str(), W_OK) != 0) {
+        d = "/tmp/dcsg_jitcache_" + std::to_string((long)getuid());
+        mkdir(d.c_str(), 0777);
+    }
+    return d;
+}
+
+struct ComgrSet {
+    amd_comgr_data_set_t s{};
+    bool ok = false;
+    ComgrSet() { ok = amd_comgr_create_data_set(&s) == AMD_COMGR_STATUS_SUCCESS; }
+    ~ComgrSet()
+    {
+        if (ok) amd_comgr_destroy_data_set(s);
+    }
+};
+
+static bool add_data(amd_comgr_data_set_t set, amd_comgr_data_kind_t kind, const char* name, const std::string& bytes)
+{
+    amd_comgr_data_t d;
+    if (amd_comgr_create_data(kind, &d) != AMD_COMGR_STATUS_SUCCESS) return false;
+    bool ok = amd_comgr_set_data(d, bytes.size(), bytes.data()) == AMD_COMGR_STATUS_SUCCESS &&
+              amd_comgr_set_data_name(d, name) == AMD_COMGR_STATUS_SUCCESS &&
+              amd_comgr_data_set_add(set, d) == AMD_COMGR_STATUS_SUCCESS;
+    amd_comgr_release_data(d);
+    return ok;
+}
+
+static std::string collect(amd_comgr_data_set_t set, amd_comgr_data_kind_t kind)
+{
+    std::string out;
+    size_t n = 0;
+    if (amd_comgr_action_data_count(set, kind, &n) != AMD_COMGR_STATUS_SUCCESS) return out;
+    for (size_t i = 0; i < n; i++) {
+        amd_comgr_data_t d;
+        if (amd_comgr_action_data_get_data(set, kind, i, &d) != AMD_COMGR_STATUS_SUCCESS) continue;
+        size_t sz = 0;
+        if (amd_comgr_get_data(d, &sz, nullptr) == AMD_COMGR_STATUS_SUCCESS && sz) {
+            std::string b(sz, '\0');
+            amd_comgr_get_data(d, &sz, &b[0]);
+            out += b;
+        }
+        amd_comgr_release_data(d);
+    }
+    return out;
+}
+
+static bool run_action(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, const std::vector<const char*>& opts,
+                       amd_comgr_data_set_t in, amd_comgr_data_set_t out, std::string& log)
+{
+    amd_comgr_action_info_t info;
+    if (amd_comgr_create_action_info(&info) != AMD_COMGR_STATUS_SUCCESS) {
+        log += "comgr: create_action_info failed\n";
+        return false;
+    }
+    bool ok = amd_comgr_action_info_set_isa_name(info, kIsa) == AMD_COMGR_STATUS_SUCCESS;
+    if (ok && lang != AMD_COMGR_LANGUAGE_NONE)
+        ok = amd_comgr_action_info_set_language(info, lang) == AMD_COMGR_STATUS_SUCCESS;
+    if (ok && !opts.empty())
+        ok = amd_comgr_action_info_set_option_list(info, const_cast<const char**>(opts.data()), opts.size()) ==
+             AMD_COMGR_STATUS_SUCCESS;
+    if (ok) ok = amd_comgr_action_info_set_logging(info, true) == AMD_COMGR_STATUS_SUCCESS;
+    amd_comgr_status_t st = AMD_COMGR_STATUS_ERROR;
+    if (ok) st = amd_comgr_do_action(kind, info, in, out);
+    amd_comgr_destroy_action_info(info);
+    std::string l = collect(out, AMD_COMGR_DATA_KIND_LOG);
+    if (st != AMD_COMGR_STATUS_SUCCESS) {
+        const char* name = nullptr;
+        amd_comgr_status_string(st, &name);
+        log += l;
+        log += std::string("comgr action ") + std::to_string((int)kind) + " failed: " + (name ? name : "?") + "\n";
+        return false;
+    }
+    return true;
+}
+
+bool jit_scene_module(const std::string& scene_cl, std::string& hsaco, std::string& log, bool* from_cache)
+{
+    if (from_cache) *from_cache = false;
+    std::string kernels_bc;
+    std::string bc_path = library_dir() + "/dcsg_kernels_extern.bc";
+    if (!read_file(bc_path, kernels_bc)) {
+        log = "cannot read " + bc_path + " (run __graft_entry__.build())";
+        return false;
+    }
+    std::string source = std::string(kScenePrelude) + scene_cl + kSceneEpilogue;
+
+    uint64_t h1 = fnv1a64(source.data(), source.size(), 0xcbf29ce484222325ull);
+    h1 = fnv1a64(kernels_bc.data(), kernels_bc.size(), h1);
+    uint64_t h2 = fnv1a64(source.data(), source.size(), 0x84222325cbf29ce4ull);
+    h2 = fnv1a64(kernels_bc.data(), kernels_bc.size(), h2);
+    char key[40];
+    snprintf(key, sizeof(key), "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
+    std::string cpath = cache_dir() + "/" + key + ".hsaco";
+    if (!getenv("DCSG_JIT_NO_CACHE") && read_file(cpath, hsaco) && hsaco.size() > 64) {
+        if (from_cache) *from_cache = true;
+        return true;
+    }
+
+    // 1. brush text (OpenCL C) -> gfx950 bitcode.  No contraction, IEEE divide/sqrt: the numerics
+    //    contract of kernels.hip.  "-w" as in the reference's build options (Utils.cpp:78-81).
+    ComgrSet src, bc;
+    if (!src.ok || !bc.ok || !add_data(src.s, AMD_COMGR_DATA_KIND_SOURCE, "scene.cl", source)) {
+        log = "comgr: cannot create source data";
+        return false;
+    }
+    if (!run_action(AMD_COMGR_ACTION_COMPILE_SOURCE_WITH_DEVICE_LIBS_TO_BC, AMD_COMGR_LANGUAGE_OPENCL_2_0,
+                    {"-ffp-contract=off", "-cl-fp32-correctly-rounded-divide-sqrt", "-w", "-O3"}, src.s, bc.s, log))
+        return false;
+    // 2. + the HIP kernels' bitcode
+    if (!add_data(bc.s, AMD_COMGR_DATA_KIND_BC, "dcsg_kernels_extern.bc", kernels_bc)) {
+        log = "comgr: cannot add kernel bitcode";
+        return false;
+    }
+    ComgrSet linked, reloc, exe;
+    if (!linked.ok || !reloc.ok || !exe.ok) {
+        log = "comgr: cannot create data sets";
+        return false;
+    }
+    if (!run_action(AMD_COMGR_ACTION_LINK_BC_TO_BC, AMD_COMGR_LANGUAGE_NONE, {}, bc.s, linked.s, log)) return false;
+    // 3. optimise across the seam (sdf_bank inlines into the interpreter) and emit ISA
+    if (!run_action(AMD_COMGR_ACTION_CODEGEN_BC_TO_RELOCATABLE, AMD_COMGR_LANGUAGE_NONE, {"-O3", "-ffp-contract=off"},
+                    linked.s, reloc.s, log))
+        return false;
+    if (!run_action(AMD_COMGR_ACTION_LINK_RELOCATABLE_TO_EXECUTABLE, AMD_COMGR_LANGUAGE_NONE, {}, reloc.s, exe.s, log))
+        return false;
+    hsaco = collect(exe.s, AMD_COMGR_DATA_KIND_EXECUTABLE);
+    if (hsaco.size() < 64) {
+        log += "comgr produced no executable\n";
+        return false;
+    }
+    write_file_atomic(cpath, hsaco);  // best effort
+    return true;
+}
+
+}  // namespace dcsg
+
+// Exposed for build.py / tests: compile one scene.cl into the cache without touching a GPU.
+extern "C" int dcsg_jit_prebuild(const char* scene_cl, char* log_out, size_t log_cap, int* from_cache)
+{
+    std::string hsaco, log;
+    bool cached = false;
+    bool ok = dcsg::jit_scene_module(scene_cl ? scene_cl : "", hsaco, log, &cached);
+    if (from_cache) *from_cache = cached ? 1 : 0;
+    if (log_out && log_cap) {
+        strncpy(log_out, log.c_str(), log_cap - 1);
+        log_out[log_cap - 1] = '\0';
+    }
+    return ok ? (int)0 : -4;
+}

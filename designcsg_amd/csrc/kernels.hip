@@ -1,0 +1,687 @@
+// kernels.hip -- gfx950 (CDNA4) device code of the DesignCSG export path.
+//
+// Replaces the reference's OpenCL kernel `k2` (k2.cl:234-280) and the host-side
+// lattice cache / octree mesher / projection loop that pulled samples through it
+// (ISV.hpp, cms/main/Headers/mesh.hpp) with:
+//   dcsg_sweep            fused SDF (+ central-difference normal) over a dense lattice slab
+//   dcsg_eval_points      k2-equivalent evaluation at arbitrary points
+//   dcsg_bbox             stage-A bounding-box probe (DesignCSG.cpp:668-712)
+//   dcsg_mesh_classify /  level-synchronous octree mesher (mesh.hpp:148-311) with
+//   dcsg_scan_blocks  /   deterministic prefix-sum compaction of children and triangles
+//   dcsg_mesh_emit
+//   dcsg_project          vertex projection ("gradient descent", mesh.hpp:531-593)
+//
+// Built twice by designcsg_amd/build.py:
+//   * stand-alone code object with the five built-in brushes written in HIP
+//   * device bitcode with DCSG_EXTERN_BANK, linked at scene-load time against the
+//     user's scene.cl (OpenCL C brush bodies) by csrc/jit.cpp
+//
+// Numerics contract (tests/ compare bit-for-bit with oracle/): IEEE binary32/64,
+// -ffp-contract=off, correctly rounded sqrt and divide, the operation order of
+// the reference expressions.  No MFMA: there is no dense contraction here.
+//
+// wave = 64 lanes; blocks are 256 threads (4 waves, one per SIMD).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dcsg_device_params.h"
+
+// k2.cl:2-4,12-17
+#define K2_MAX_DISTANCE 64.0
+#define K2_NORMAL_EPSILON 0.005
+#define OP_IMPORT 0
+#define OP_EXPORT 1
+#define OP_MIN 2
+#define OP_MAX 3
+#define OP_NEGATE 4
+#define OP_IDENTITY 5
+
+// ---------------------------------------------------------------------------
+// Brush bank
+// ---------------------------------------------------------------------------
+#ifdef DCSG_EXTERN_BANK
+// OpenCL C float3 is a 16-byte ext-vector, not HIP's 12-byte struct.
+typedef float dcsg_cl_float3 __attribute__((ext_vector_type(3)));
+extern "C" __device__ float sdf_bank(dcsg_cl_float3 v, unsigned char shape_id);  // generated scene.cl
+extern "C" __device__ void dcsg_scene_set_ad(__attribute__((address_space(1))) float* p);  // scene_prelude.cl
+__device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_id)
+{
+    dcsg_cl_float3 v = {x, y, z};
+    return sdf_bank(v, (unsigned char)shape_id);
+}
+#else
+// OpenCL max(gentype x, gentype y): y if x < y, otherwise x
+__device__ __forceinline__ double cl_max_d(double x, double y) { return x < y ? y : x; }
+// The five brushes every scene starts with (scenecompiler.py:424-425, DesignCSG.py:9-22).
+// Unsuffixed literals are double in OpenCL C: subtract in double, narrow at return.
+__device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_id)
+{
+    switch (shape_id & 0xff) {  // wave-uniform
+    case 0: return (float)K2_MAX_DISTANCE;
+    case 1: return 0.0f;
+    case 2: return (float)((double)__builtin_sqrtf(x * x + y * y + z * z) - 0.5);
+    case 3: {
+        float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
+        float r = __builtin_sqrtf(ax * ax + az * az);
+        return (float)cl_max_d((double)r - 0.5, (double)ay - 0.5);
+    }
+    case 4: {
+        float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
+        return (float)cl_max_d((double)ax - 0.5, cl_max_d((double)ay - 0.5, (double)az - 0.5));
+    }
+    default: return 0.0f;  // sdf_bank's trailing "return 0.0;"
+    }
+}
+#endif
+
+// ---------------------------------------------------------------------------
+// Scene tables in LDS.
+// Blob (built by csrc/scene.cpp): [0] header {n_steps,n_objects,n_slots,flags}, flags bit 0 =
+// "brush 0 is the constant null brush `return MAX_DISTANCE;`" (always true for the built-in bank;
+// for a JIT-linked scene.cl only when the host verified sd0's body);
+// [1 .. n_steps] steps {opcode,left,right,dest}; then 4 x float4 per object:
+// {pos.xyz, shape_id bits}, {right.xyz,0}, {up.xyz,0}, {forward.xyz,0}.
+// After the blob: the interpreter stack, slot-major (slot*DCSG_BLOCK + tid), so
+// every access is one conflict-free ds_read/ds_write_b32.
+// ---------------------------------------------------------------------------
+extern __shared__ uint4 dcsg_lds[];
+
+struct SceneLds {
+    const int4* steps;
+    const float4* obj;
+    float* stack;  // already offset by threadIdx.x
+    int n_steps;
+    int flags;
+};
+
+__device__ __forceinline__ SceneLds dcsg_stage_scene(const uint4* __restrict__ blob, int n_vec4)
+{
+    for (int i = threadIdx.x; i < n_vec4; i += DCSG_BLOCK) dcsg_lds[i] = blob[i];
+    __syncthreads();
+    SceneLds s;
+    int n_steps = __builtin_amdgcn_readfirstlane((int)dcsg_lds[0].x);
+    s.n_steps = n_steps;
+    s.flags = __builtin_amdgcn_readfirstlane((int)dcsg_lds[0].w);
+    s.steps = reinterpret_cast<const int4*>(dcsg_lds + 1);
+    s.obj = reinterpret_cast<const float4*>(dcsg_lds + 1 + n_steps);
+    s.stack = reinterpret_cast<float*>(dcsg_lds + n_vec4) + threadIdx.x;
+    return s;
+}
+
+// primary_sdf, k2.cl:47-144: register machine over the build procedure.
+// Step words are wave-uniform: read once from LDS (broadcast) and moved to SGPRs so the
+// opcode switch and the brush switch are scalar branches, not exec-mask divergence.
+__device__ __forceinline__ float dcsg_primary_sdf(const SceneLds& s, float x, float y, float z)
+{
+    float export_value = (float)K2_MAX_DISTANCE;
+    for (int c = 0; c < s.n_steps; c++) {
+        int4 st = s.steps[c];
+        int op = __builtin_amdgcn_readfirstlane(st.x);
+        int left = __builtin_amdgcn_readfirstlane(st.y);
+        int right = __builtin_amdgcn_readfirstlane(st.z);
+        int dest = __builtin_amdgcn_readfirstlane(st.w);
+        switch (op) {
+        case OP_IMPORT: {  // k2.cl:104-113
+            int shape = left & 0xff;
+            float r;
+            if (shape == 0 && (s.flags & 1)) {
+                // sd0 ignores v ("return MAX_DISTANCE;"): skip the dead transform
+                r = (float)K2_MAX_DISTANCE;
+            } else {
+                float4 q0 = s.obj[4 * right + 0];
+                float4 q1 = s.obj[4 * right + 1];
+                float4 q2 = s.obj[4 * right + 2];
+                float4 q3 = s.obj[4 * right + 3];
+                float dx = x - q0.x, dy = y - q0.y, dz = z - q0.z;
+                float A = dx * q1.x + dy * q1.y + dz * q1.z;  // dot(v-o, right)
+                float B = dx * q2.x + dy * q2.y + dz * q2.z;  // dot(v-o, up)
+                float C = dx * q3.x + dy * q3.y + dz * q3.z;  // dot(v-o, forward)
+                r = dcsg_bank(A, B, C, shape);
+            }
+            s.stack[dest * DCSG_BLOCK] = r;
+        } break;
+        case OP_EXPORT: export_value = s.stack[left * DCSG_BLOCK]; break;
+        case OP_MIN: {  // T_min(a,b) (a<b?a:b), k2.cl:29
+            float a = s.stack[left * DCSG_BLOCK], b = s.stack[right * DCSG_BLOCK];
+            s.stack[dest * DCSG_BLOCK] = a < b ? a : b;
+        } break;
+        case OP_MAX: {  // T_max(a,b) (a>b?a:b), k2.cl:30
+            float a = s.stack[left * DCSG_BLOCK], b = s.stack[right * DCSG_BLOCK];
+            s.stack[dest * DCSG_BLOCK] = a > b ? a : b;
+        } break;
+        case OP_NEGATE: s.stack[dest * DCSG_BLOCK] = -s.stack[left * DCSG_BLOCK]; break;
+        case OP_IDENTITY: s.stack[dest * DCSG_BLOCK] = s.stack[left * DCSG_BLOCK]; break;
+        default: break;
+        }
+    }
+    return export_value;
+}
+
+// OpenCL normalize(float3) pinned as v / length(v), zero vector stays zero.
+__device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
+{
+    float len = __builtin_sqrtf(x * x + y * y + z * z);
+    if (len == 0.0f) {
+        x = y = z = 0.0f;
+    } else {
+        x = x / len;
+        y = y / len;
+        z = z / len;
+    }
+}
+
+// get_normal, k2.cl:149-179
+__device__ __forceinline__ void dcsg_get_normal(const SceneLds& s, float x, float y, float z, float& nx, float& ny,
+                                                float& nz)
+{
+    const float e = (float)K2_NORMAL_EPSILON;
+    const float zero = 0.0f;  // v+dx adds +0.0 on the other axes (k2.cl:167-173)
+    float Dx = dcsg_primary_sdf(s, x + e, y + zero, z + zero) - dcsg_primary_sdf(s, x - e, y - zero, z - zero);
+    float Dy = dcsg_primary_sdf(s, x + zero, y + e, z + zero) - dcsg_primary_sdf(s, x - zero, y - e, z - zero);
+    float Dz = dcsg_primary_sdf(s, x + zero, y + zero, z + e) - dcsg_primary_sdf(s, x - zero, y - zero, z - e);
+    const float twoE = (float)(2.0 * K2_NORMAL_EPSILON);
+    const double k = 1.0 / (double)twoE;  // "1.0/twoE*Dx": double product, narrowed (k2.cl:177)
+    nx = (float)(k * (double)Dx);
+    ny = (float)(k * (double)Dy);
+    nz = (float)(k * (double)Dz);
+    dcsg_normalize(nx, ny, nz);
+}
+
+// ISV3D64::getPoint, ISV.hpp:103-109
+__device__ __forceinline__ float dcsg_lattice_coord(const DcsgLattice& L, int axis, int i)
+{
+    float t = L.diam[axis] * (float)i;
+    t = L.w_pow2 ? t * L.inv_w : t / L.w;
+    return L.base[axis] + t;
+}
+
+// ISV3D64::getCoords, ISV.hpp:91-96 (float arithmetic, truncation toward zero)
+__device__ __forceinline__ int dcsg_snap(const DcsgLattice& L, int axis, float p)
+{
+    float t = L.w * (p - L.center[axis] + L.half[axis]) / L.diam[axis];
+    int i = (int)t;
+    i = i < 0 ? 0 : (i > L.res ? L.res : i);
+    return i;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 1: fused lattice sweep.  One thread per lattice point, x fastest, so a
+// wave stores 256 contiguous bytes of SDF and 768 contiguous bytes of normals.
+// `first` is the flat index of this launch's first point inside the slab buffer,
+// plane z0 is the slab's first plane.  Algorithmic traffic: 16 B written per
+// point, nothing read (positions come from the index, tables from LDS).
+// ---------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_sweep(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,
+           unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    const unsigned int n1 = (unsigned int)L.res + 1u;
+    const unsigned int tiles = (n_points + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        unsigned int local = tile * DCSG_BLOCK + threadIdx.x;
+        if (local >= n_points) continue;
+        unsigned int idx = first + local;
+        unsigned int ix = idx % n1;
+        unsigned int t = idx / n1;
+        unsigned int iy = t % n1;
+        unsigned int iz = t / n1;
+        float x = dcsg_lattice_coord(L, 0, (int)ix);
+        float y = dcsg_lattice_coord(L, 1, (int)iy);
+        float z = dcsg_lattice_coord(L, 2, (int)iz + z0);
+        if (sdf_out) sdf_out[idx] = dcsg_primary_sdf(s, x, y, z);
+        if (nrm_out) {
+            float nx, ny, nz;
+            dcsg_get_normal(s, x, y, z, nx, ny, nz);
+            float* o = nrm_out + (size_t)idx * 3;
+            o[0] = nx;
+            o[1] = ny;
+            o[2] = nz;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 2: k2-equivalent point evaluation (Evaluator::eval_sdf_at_points /
+// eval_normal_at_points).  mode 0 = SDF (1 float/pt), 1 = normal (3 floats/pt).
+// ---------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_eval_points(const uint4* __restrict__ blob, int n_vec4, const float* __restrict__ xyz, unsigned int n, int mode,
+                 float* __restrict__ out)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    const unsigned int tiles = (n + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        unsigned int i = tile * DCSG_BLOCK + threadIdx.x;
+        if (i >= n) continue;
+        float x = xyz[(size_t)i * 3 + 0], y = xyz[(size_t)i * 3 + 1], z = xyz[(size_t)i * 3 + 2];
+        if (mode == 0) {
+            out[i] = dcsg_primary_sdf(s, x, y, z);
+        } else {
+            float nx, ny, nz;
+            dcsg_get_normal(s, x, y, z, nx, ny, nz);
+            out[(size_t)i * 3 + 0] = nx;
+            out[(size_t)i * 3 + 1] = ny;
+            out[(size_t)i * 3 + 2] = nz;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// wave / block reductions and scans
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min(int v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(v, o, DCSG_WAVE);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(v, o, DCSG_WAVE);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned int wave_sum(unsigned int v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, DCSG_WAVE);
+    return v;
+}
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v)
+{
+    const int lane = threadIdx.x & (DCSG_WAVE - 1);
+    for (int o = 1; o < DCSG_WAVE; o <<= 1) {
+        unsigned int t = __shfl_up(v, o, DCSG_WAVE);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 3: stage A bounding-box probe, DesignCSG.cpp:668-712.
+// 256^3 points, p = -cd/2 + cd*(float)i, i in [-128,127], z innermost.  Position is
+// monotone in the index, so min/max positions reduce as integer indices.
+// result: int[0..2] min index, int[3..5] max index (both seeded by the host with the
+// "no interior point" sentinels), unsigned long long at byte 32: interior count.
+// ---------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_bbox(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, double bb_eps, int* __restrict__ result)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    const unsigned int total = 256u * 256u * 256u;
+    int mn[3] = {1 << 20, 1 << 20, 1 << 20};
+    int mx[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
+    unsigned int cnt = 0;
+    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < total; i += gridDim.x * DCSG_BLOCK) {
+        int iz = (int)(i & 255u) - 128;
+        int iy = (int)((i >> 8) & 255u) - 128;
+        int ix = (int)(i >> 16) - 128;
+        float x = half_neg + cd * (float)ix;
+        float y = half_neg + cd * (float)iy;
+        float z = half_neg + cd * (float)iz;
+        float v = dcsg_primary_sdf(s, x, y, z);
+        if ((double)v < bb_eps) {  // "p.second < BB_EPSILON", float vs double
+            cnt++;
+            mn[0] = ix < mn[0] ? ix : mn[0];
+            mx[0] = ix > mx[0] ? ix : mx[0];
+            mn[1] = iy < mn[1] ? iy : mn[1];
+            mx[1] = iy > mx[1] ? iy : mx[1];
+            mn[2] = iz < mn[2] ? iz : mn[2];
+            mx[2] = iz > mx[2] ? iz : mx[2];
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+        mn[k] = wave_min(mn[k]);
+        mx[k] = wave_max(mx[k]);
+    }
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & (DCSG_WAVE - 1)) == 0) {
+        for (int k = 0; k < 3; k++) {
+            atomicMin(&result[k], mn[k]);
+            atomicMax(&result[3 + k], mx[k]);
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(result + 8), (unsigned long long)cnt);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Mesher (Mesh::getSurface, mesh.hpp:148-311) on the dense lattice.
+// Level-synchronous: one thread per node of the level.
+// ---------------------------------------------------------------------------
+// Box3f::getCorners(s), geometry.hpp:264-279: corner k = center + ((hd*sign_k)*s) with
+// sign_k = (-,-,+),(+,-,+),(+,-,-),(-,-,-),(-,+,+),(+,+,+),(+,+,-),(-,+,-).  hd*(+-1) and
+// the scaling by s in {1.0f, 0.5f} are exact, so this is center +- s*hd per axis.  Signs come
+// from the bits of k (no runtime-indexed private array, which would live in scratch).
+__device__ __forceinline__ void dcsg_corner(int k, float s, const float c[3], const float hd[3], float out[3])
+{
+    int q = k & 3;
+    float sx = (q == 1 || q == 2) ? 1.0f : -1.0f;
+    float sy = k >= 4 ? 1.0f : -1.0f;
+    float sz = q < 2 ? 1.0f : -1.0f;
+    out[0] = c[0] + s * (hd[0] * sx);
+    out[1] = c[1] + s * (hd[1] * sy);
+    out[2] = c[2] + s * (hd[2] * sz);
+}
+// 12 edges: 0-3 bottom ring (i,(i+1)%4), 4-7 top ring, 8-11 verticals (i,i+4); mesh.hpp:187-209
+__device__ __forceinline__ int dcsg_edge_a(int e) { return e < 8 ? e : e - 8; }
+__device__ __forceinline__ int dcsg_edge_b(int e)
+{
+    return e < 4 ? ((e + 1) & 3) : (e < 8 ? (((e - 3) & 3) + 4) : e - 4);
+}
+
+struct Sampler {
+    const DcsgMeshParams* P;
+    const float* sdf;
+    const float* nrm;
+    const SceneLds* scene;
+};
+
+// The value AT THE SNAPPED LATTICE POINT (ISV3D64::getValue, ISV.hpp:15-60).  Planes that
+// are not resident on this rank are evaluated directly: a sample is a pure function of its
+// lattice index, so both paths give the same bits.
+__device__ __forceinline__ float sample_sdf(const Sampler& S, const float p[3])
+{
+    const DcsgLattice& L = S.P->lat;
+    int ix = dcsg_snap(L, 0, p[0]), iy = dcsg_snap(L, 1, p[1]), iz = dcsg_snap(L, 2, p[2]);
+    if (iz >= S.P->z_lo && iz <= S.P->z_hi) {
+        size_t n1 = (size_t)L.res + 1;
+        return S.sdf[((size_t)(iz - S.P->z_lo) * n1 + iy) * n1 + ix];
+    }
+    return dcsg_primary_sdf(*S.scene, dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy),
+                            dcsg_lattice_coord(L, 2, iz));
+}
+
+__device__ __forceinline__ void sample_normal(const Sampler& S, const float p[3], float n[3])
+{
+    const DcsgLattice& L = S.P->lat;
+    int ix = dcsg_snap(L, 0, p[0]), iy = dcsg_snap(L, 1, p[1]), iz = dcsg_snap(L, 2, p[2]);
+    if (S.P->has_normals && iz >= S.P->z_lo && iz <= S.P->z_hi) {
+        size_t n1 = (size_t)L.res + 1;
+        const float* q = S.nrm + (((size_t)(iz - S.P->z_lo) * n1 + iy) * n1 + ix) * 3;
+        n[0] = q[0];
+        n[1] = q[1];
+        n[2] = q[2];
+        return;
+    }
+    dcsg_get_normal(*S.scene, dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy),
+                    dcsg_lattice_coord(L, 2, iz), n[0], n[1], n[2]);
+}
+
+// Node codes in info[i] (low byte; lookup case in the high byte)
+#define NODE_SKIP 0u       // culled (mesh.hpp:170) or outside this rank's Z-slab
+#define NODE_SUBDIVIDE 1u  // 8 children go to the next level
+#define NODE_LEAF 2u       // emits trsMap[lookup] triangles
+#define NODE_LEAF_REMOTE 3u  // leaf whose triangles another rank emits
+
+// Node classification.  block_sums[2*b+0] = children of block b, [2*b+1] = triangles of
+// block b.  level_stats: {culled, subdivided, leaves, triangles}, integer atomics, counting
+// only nodes this rank owns so that per-rank stats add up to the single-GPU ones.
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P, const float* __restrict__ nodes,
+                   unsigned int n_nodes, const float* __restrict__ sdf, const float* __restrict__ nrm,
+                   const unsigned char* __restrict__ tri_table, unsigned short* __restrict__ info,
+                   unsigned int* __restrict__ block_sums, unsigned long long* __restrict__ level_stats)
+{
+    SceneLds scene = dcsg_stage_scene(blob, n_vec4);
+    Sampler S = {&P, sdf, nrm, &scene};
+    unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x;
+    unsigned int code = NODE_SKIP, lookup = 0, n_tri = 0;
+    bool owned = false, culled = false;
+    if (i < n_nodes) {
+        float c[3] = {nodes[(size_t)i * 3 + 0], nodes[(size_t)i * 3 + 1], nodes[(size_t)i * 3 + 2]};
+        // Z-slab ownership: the node's plane range [zlo, zhi]
+        int zlo = dcsg_snap(P.lat, 2, c[2] + 1.0f * (P.hd[2] * -1.0f));
+        int zhi = dcsg_snap(P.lat, 2, c[2] + 1.0f * (P.hd[2] * 1.0f));
+        bool intersects = zlo < P.z_own_hi && zhi > P.z_own_lo;
+        owned = zlo >= P.z_own_lo && zlo < P.z_own_hi;
+        if (intersects) {
+            // mesh.hpp:167-170
+            float d = sample_sdf(S, c);
+            float mag = __builtin_sqrtf(P.hd[0] * P.hd[0] + P.hd[1] * P.hd[1] + P.hd[2] * P.hd[2]);
+            culled = __builtin_fabsf(d) > mag * 1.1f;
+            if (!culled) {
+                // mesh.hpp:176-183
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    float p[3];
+                    dcsg_corner(k, 1.0f, c, P.hd, p);
+                    lookup |= (sample_sdf(S, p) < 0.0f ? 1u : 0u) << k;
+                }
+                bool subdivide = false;
+                if (P.level < P.min_level) {  // mesh.hpp:214-217
+                    subdivide = true;
+                } else if (P.level != P.max_level) {  // at max level the tests cannot change the outcome (:265-267)
+                    // edge ambiguity, mesh.hpp:221-238
+                    int n_along = 1 << (P.grid_level - P.level);
+                    for (int e = 0; e < 12 && !subdivide; e++) {
+                        float a[3], b[3];
+                        dcsg_corner(dcsg_edge_a(e), 1.0f, c, P.hd, a);
+                        dcsg_corner(dcsg_edge_b(e), 1.0f, c, P.hd, b);
+                        float dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+                        for (int j = 1; j < n_along; j++) {
+                            float f = (float)j / (float)n_along;
+                            float t[3] = {a[0] + f * dx, a[1] + f * dy, a[2] + f * dz};
+                            if (sample_sdf(S, t) < 0.0f) {
+                                subdivide = true;
+                                break;
+                            }
+                        }
+                    }
+                    // complex edges, mesh.hpp:244-258 (angleBetweenVectors, geometry.hpp:118-124)
+                    for (int e = 0; e < 12 && !subdivide; e++) {
+                        float a[3], b[3], na[3], nb[3];
+                        dcsg_corner(dcsg_edge_a(e), 1.0f, c, P.hd, a);
+                        dcsg_corner(dcsg_edge_b(e), 1.0f, c, P.hd, b);
+                        sample_normal(S, a, na);
+                        sample_normal(S, b, nb);
+                        float ma = __builtin_sqrtf(na[0] * na[0] + na[1] * na[1] + na[2] * na[2]);
+                        float mb = __builtin_sqrtf(nb[0] * nb[0] + nb[1] * nb[1] + nb[2] * nb[2]);
+                        if (!(ma * mb < 1e-6f)) {
+                            float q = (na[0] * nb[0] + na[1] * nb[1] + na[2] * nb[2]) / (ma * mb);
+                            // (float)acos((double)q) > threshold, folded by the host into q_star
+                            if (q >= -1.0f && q <= P.q_star) subdivide = true;
+                        }
+                    }
+                }
+                if (subdivide) {
+                    code = NODE_SUBDIVIDE;
+                } else if (owned) {
+                    code = NODE_LEAF;
+                    n_tri = tri_table[lookup * 16];
+                } else {
+                    code = NODE_LEAF_REMOTE;
+                }
+            }
+        }
+        info[i] = (unsigned short)(code | (lookup << 8));
+    }
+    // block totals for the compaction scan + per-level statistics
+    unsigned int child = code == NODE_SUBDIVIDE ? 8u : 0u;
+    unsigned int wc = wave_sum(child), wt = wave_sum(n_tri);
+    unsigned int ws = wave_sum((owned && code == NODE_SUBDIVIDE) ? 1u : 0u);
+    unsigned int wl = wave_sum(code == NODE_LEAF ? 1u : 0u);
+    unsigned int wq = wave_sum((owned && culled) ? 1u : 0u);
+    __shared__ unsigned int part[5][DCSG_BLOCK / DCSG_WAVE];
+    int wave = threadIdx.x / DCSG_WAVE;
+    if ((threadIdx.x & (DCSG_WAVE - 1)) == 0) {
+        part[0][wave] = wc;
+        part[1][wave] = wt;
+        part[2][wave] = wl;
+        part[3][wave] = wq;
+        part[4][wave] = ws;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int cs = 0, t = 0, l = 0, q = 0, sb = 0;
+        for (int k = 0; k < DCSG_BLOCK / DCSG_WAVE; k++) {
+            cs += part[0][k];
+            t += part[1][k];
+            l += part[2][k];
+            q += part[3][k];
+            sb += part[4][k];
+        }
+        block_sums[2 * blockIdx.x + 0] = cs;
+        block_sums[2 * blockIdx.x + 1] = t;
+        if (q) atomicAdd(&level_stats[0], (unsigned long long)q);
+        if (sb) atomicAdd(&level_stats[1], (unsigned long long)sb);
+        if (l) atomicAdd(&level_stats[2], (unsigned long long)l);
+        if (t) atomicAdd(&level_stats[3], (unsigned long long)t);
+    }
+}
+
+// Exclusive scan of the per-block {children, triangles} pairs, single block.
+// totals[0] = children, totals[1] = triangles.
+extern "C" __global__ void __launch_bounds__(1024)
+dcsg_scan_blocks(unsigned int* __restrict__ block_sums, unsigned int n_blocks, unsigned int* __restrict__ totals)
+{
+    __shared__ unsigned int wsum[2][1024 / DCSG_WAVE];
+    __shared__ unsigned int carry[2];
+    if (threadIdx.x == 0) carry[0] = carry[1] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & (DCSG_WAVE - 1), wave = threadIdx.x / DCSG_WAVE;
+    for (unsigned int base = 0; base < n_blocks; base += 1024) {
+        unsigned int i = base + threadIdx.x;
+        unsigned int c = i < n_blocks ? block_sums[2 * i] : 0u;
+        unsigned int t = i < n_blocks ? block_sums[2 * i + 1] : 0u;
+        unsigned int ic = wave_scan_incl(c), it = wave_scan_incl(t);
+        if (lane == DCSG_WAVE - 1) {
+            wsum[0][wave] = ic;
+            wsum[1][wave] = it;
+        }
+        __syncthreads();
+        unsigned int oc = carry[0], ot = carry[1];
+        for (int k = 0; k < wave; k++) {
+            oc += wsum[0][k];
+            ot += wsum[1][k];
+        }
+        if (i < n_blocks) {
+            block_sums[2 * i] = oc + ic - c;
+            block_sums[2 * i + 1] = ot + it - t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            carry[0] = oc + ic;
+            carry[1] = ot + it;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = carry[0];
+        totals[1] = carry[1];
+    }
+}
+
+// Emit: children of subdivided nodes (Node::subdivideIntoQueue, octree.hpp:24-32) into the
+// next level's node list, triangles of leaves (mesh.hpp:283-307) into the triangle buffer.
+// Offsets = scanned block base + in-block wave prefix sums, so the output order is a pure
+// function of the node order: deterministic, unlike the reference's thread interleaving.
+// The 256-case triangle table (lookupTable.txt expanded) is staged in LDS.
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_mesh_emit(DcsgMeshParams P, const float* __restrict__ nodes, unsigned int n_nodes,
+               const unsigned short* __restrict__ info, const unsigned int* __restrict__ block_base,
+               const unsigned char* __restrict__ tri_table, float* __restrict__ next_nodes,
+               float* __restrict__ tris, unsigned long long tri_base)
+{
+    __shared__ unsigned char table[256 * 16];  // per case: count, then up to 5 x 3 edge ids
+    for (int k = threadIdx.x; k < 256 * 16 / 4; k += DCSG_BLOCK)
+        reinterpret_cast<unsigned int*>(table)[k] = reinterpret_cast<const unsigned int*>(tri_table)[k];
+    __shared__ unsigned int wsum[2][DCSG_BLOCK / DCSG_WAVE];
+    unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x;
+    unsigned int code = NODE_SKIP, lookup = 0;
+    if (i < n_nodes) {
+        unsigned int v = info[i];
+        code = v & 0xffu;
+        lookup = v >> 8;
+    }
+    __syncthreads();
+    unsigned int child = code == NODE_SUBDIVIDE ? 8u : 0u;
+    unsigned int n_tri = code == NODE_LEAF ? table[lookup * 16] : 0u;
+    unsigned int ic = wave_scan_incl(child), it = wave_scan_incl(n_tri);
+    const int lane = threadIdx.x & (DCSG_WAVE - 1), wave = threadIdx.x / DCSG_WAVE;
+    if (lane == DCSG_WAVE - 1) {
+        wsum[0][wave] = ic;
+        wsum[1][wave] = it;
+    }
+    __syncthreads();
+    unsigned int oc = block_base[2 * blockIdx.x], ot = block_base[2 * blockIdx.x + 1];
+    for (int k = 0; k < wave; k++) {
+        oc += wsum[0][k];
+        ot += wsum[1][k];
+    }
+    oc += ic - child;
+    ot += it - n_tri;
+    if (code != NODE_SUBDIVIDE && n_tri == 0) return;
+    float c[3] = {nodes[(size_t)i * 3 + 0], nodes[(size_t)i * 3 + 1], nodes[(size_t)i * 3 + 2]};
+    if (code == NODE_SUBDIVIDE) {
+        // child centre = getCorners(0.5)[k]; child half diameter = 0.5f*hd (host side)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float p[3];
+            dcsg_corner(k, 0.5f, c, P.hd, p);
+            float* o = next_nodes + (size_t)(oc + k) * 3;
+            o[0] = p[0];
+            o[1] = p[1];
+            o[2] = p[2];
+        }
+    } else {
+        const unsigned char* row = table + lookup * 16;
+        for (unsigned int t = 0; t < n_tri; t++) {
+            float* o = tris + (size_t)(tri_base + ot + t) * 9;
+            for (int v = 0; v < 3; v++) {
+                int e = row[1 + 3 * t + v];
+                float a[3], b[3];
+                dcsg_corner(dcsg_edge_a(e), 1.0f, c, P.hd, a);
+                dcsg_corner(dcsg_edge_b(e), 1.0f, c, P.hd, b);
+                // Vector3f::midpoint = a.scaled(0.5) + b.scaled(0.5), geometry.hpp:91-93
+                o[3 * v + 0] = 0.5f * a[0] + 0.5f * b[0];
+                o[3 * v + 1] = 0.5f * a[1] + 0.5f * b[1];
+                o[3 * v + 2] = 0.5f * a[2] + 0.5f * b[2];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Kernel: vertex projection, performGradientDescent mesh.hpp:531-593.
+// p <- p + n(p) * (-sdf(p)), `steps` times, at the true (unsnapped) positions.  All steps of
+// a vertex run in registers: 12 B read + 12 B written per vertex for the whole loop instead of
+// the reference's 100 blocking evaluator round trips.
+// ---------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_project(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ verts, unsigned int n_verts, int steps)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    const unsigned int tiles = (n_verts + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        unsigned int i = tile * DCSG_BLOCK + threadIdx.x;
+        if (i >= n_verts) continue;
+        float x = verts[(size_t)i * 3 + 0], y = verts[(size_t)i * 3 + 1], z = verts[(size_t)i * 3 + 2];
+        for (int k = 0; k < steps; k++) {
+            float sd = dcsg_primary_sdf(s, x, y, z);
+            float nx, ny, nz;
+            dcsg_get_normal(s, x, y, z, nx, ny, nz);
+            float m = -sd;  // v3f_scale(n, -s) then v3f_add, CVector.cpp:128-149
+            x = x + m * nx;
+            y = y + m * ny;
+            z = z + m * nz;
+        }
+        verts[(size_t)i * 3 + 0] = x;
+        verts[(size_t)i * 3 + 1] = y;
+        verts[(size_t)i * 3 + 2] = z;
+    }
+}
+
+#ifdef DCSG_EXTERN_BANK
+// Points the scene module's program-scope `arbitrary_data` (k2.cl:41,251) at the uploaded table.
+extern "C" __global__ void dcsg_set_arbitrary_data(float* ad)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        dcsg_scene_set_ad((__attribute__((address_space(1))) float*)ad);
+}
+#endif

@@ -1,0 +1,379 @@
+// scene.cpp -- parsers for scene.txt / buildprocedure.txt / exportConfig.txt / lookupTable.txt.
+#include "scene.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "dcsg_device_params.h"
+
+namespace dcsg {
+
+static const char* skip_ws(const char* p)
+{
+    while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') p++;
+    return p;
+}
+
+// DrawPane.cpp:280-353: per line "%d %d" then 12 x "%f", single-space separated.
+// DrawPane.cpp:355-371: per line "%d %d %d %d".
+bool parse_scene(const char* scene_txt, const char* bp_txt, Scene& s, std::string& err)
+{
+    s = Scene();
+    if (!scene_txt || !bp_txt) {
+        err = "scene_txt / buildprocedure_txt is NULL";
+        return false;
+    }
+    const char* p = skip_ws(scene_txt);
+    while (*p) {
+        char* end;
+        long brush = strtol(p, &end, 10);
+        if (end == p) {
+            err = "scene.txt: expected brush id at object " + std::to_string(s.n_objects);
+            return false;
+        }
+        p = end;
+        (void)strtol(p, &end, 10);  // material id: not used by the export path
+        if (end == p) {
+            err = "scene.txt: expected material id at object " + std::to_string(s.n_objects);
+            return false;
+        }
+        p = end;
+        float v[12];
+        for (int k = 0; k < 12; k++) {
+            v[k] = strtof(p, &end);
+            if (end == p) {
+                err = "scene.txt: object " + std::to_string(s.n_objects) + " has fewer than 12 floats";
+                return false;
+            }
+            p = end;
+        }
+        s.shape.push_back((uint8_t)brush);
+        for (int k = 0; k < 3; k++) {
+            s.pos.push_back(v[k]);
+            s.right.push_back(v[3 + k]);
+            s.up.push_back(v[6 + k]);
+            s.fwd.push_back(v[9 + k]);
+        }
+        s.n_objects++;
+        p = skip_ws(p);
+    }
+    p = skip_ws(bp_txt);
+    while (*p) {
+        int v[4];
+        for (int k = 0; k < 4; k++) {
+            char* end;
+            v[k] = (int)strtol(p, &end, 10);
+            if (end == p) {
+                err = "buildprocedure.txt: step " + std::to_string(s.n_steps) + " has fewer than 4 integers";
+                return false;
+            }
+            p = end;
+        }
+        for (int k = 0; k < 4; k++) s.steps.push_back(v[k]);
+        s.n_steps++;
+        p = skip_ws(p);
+    }
+    // Validation: everything the kernels index with must be in range.
+    int max_slot = -1;
+    auto slot_ok = [&](int a, const char* what, int step) {
+        if (a < 0 || a >= DCSG_MAX_SLOTS) {
+            err = std::string("buildprocedure.txt: step ") + std::to_string(step) + " " + what + " slot " +
+                  std::to_string(a) + " outside 0.." + std::to_string(DCSG_MAX_SLOTS - 1) +
+                  " (STACK_MEMORY_PER_PIXEL, Evaluator.cpp:7)";
+            return false;
+        }
+        if (a > max_slot) max_slot = a;
+        return true;
+    };
+    for (int c = 0; c < s.n_steps; c++) {
+        int op = s.steps[4 * c], l = s.steps[4 * c + 1], r = s.steps[4 * c + 2], d = s.steps[4 * c + 3];
+        switch (op) {
+        case 0:  // IMPORT brush=l object=r -> d
+            if (r < 0 || r >= s.n_objects) {
+                err = "buildprocedure.txt: step " + std::to_string(c) + " imports object " + std::to_string(r) +
+                      " but scene.txt has " + std::to_string(s.n_objects);
+                return false;
+            }
+            if (!slot_ok(d, "destination", c)) return false;
+            if ((l & 0xff) > s.max_brush_id) s.max_brush_id = l & 0xff;
+            break;
+        case 1:  // EXPORT l
+            if (!slot_ok(l, "source", c)) return false;
+            break;
+        case 2:
+        case 3:  // MIN / MAX l r -> d
+            if (!slot_ok(l, "left", c) || !slot_ok(r, "right", c) || !slot_ok(d, "destination", c)) return false;
+            break;
+        case 4:
+        case 5:  // NEGATE / IDENTITY l -> d
+            if (!slot_ok(l, "source", c) || !slot_ok(d, "destination", c)) return false;
+            break;
+        default:  // k2.cl's switch ignores unknown opcodes; so do the kernels
+            break;
+        }
+    }
+    s.n_slots = max_slot + 1;
+    if (s.n_slots < 1) s.n_slots = 1;
+    return true;
+}
+
+size_t Scene::lds_bytes() const { return blob.size() * 4 + (size_t)n_slots * DCSG_BLOCK * sizeof(float); }
+
+void build_blob(Scene& s, bool null_brush_is_const)
+{
+    auto f2u = [](float f) {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        return u;
+    };
+    s.blob.clear();
+    s.blob.push_back((uint32_t)s.n_steps);
+    s.blob.push_back((uint32_t)s.n_objects);
+    s.blob.push_back((uint32_t)s.n_slots);
+    s.blob.push_back(null_brush_is_const ? 1u : 0u);
+    for (int c = 0; c < 4 * s.n_steps; c++) s.blob.push_back((uint32_t)s.steps[c]);
+    for (int i = 0; i < s.n_objects; i++) {
+        s.blob.push_back(f2u(s.pos[3 * i]));
+        s.blob.push_back(f2u(s.pos[3 * i + 1]));
+        s.blob.push_back(f2u(s.pos[3 * i + 2]));
+        s.blob.push_back((uint32_t)s.shape[i]);
+        const std::vector<float>* axes[3] = {&s.right, &s.up, &s.fwd};
+        for (auto* a : axes) {
+            s.blob.push_back(f2u((*a)[3 * i]));
+            s.blob.push_back(f2u((*a)[3 * i + 1]));
+            s.blob.push_back(f2u((*a)[3 * i + 2]));
+            s.blob.push_back(0u);
+        }
+    }
+}
+
+// ---- scene.cl inspection ---------------------------------------------------------------------
+static std::string strip_ws(const std::string& t)
+{
+    std::string o;
+    for (char ch : t)
+        if (ch != ' ' && ch != '\t' && ch != '\r' && ch != '\n') o.push_back(ch);
+    return o;
+}
+
+// Body of "float sd<N>( float3 v){ ... }" as emitted by Brush.__str__ (scenecompiler.py:234-241),
+// whitespace removed; empty if not found.
+static std::string brush_body(const std::string& cl, int n)
+{
+    std::string key = "float sd" + std::to_string(n) + "(";
+    size_t p = cl.find(key);
+    if (p == std::string::npos) return "";
+    size_t open = cl.find('{', p);
+    if (open == std::string::npos) return "";
+    int depth = 0;
+    for (size_t i = open; i < cl.size(); i++) {
+        if (cl[i] == '{') depth++;
+        if (cl[i] == '}' && --depth == 0) return strip_ws(cl.substr(open + 1, i - open - 1));
+    }
+    return "";
+}
+
+bool scene_cl_null_brush_is_const(const std::string& cl)
+{
+    if (brush_body(cl, 0) != "returnMAX_DISTANCE;") return false;
+    // any preprocessor line naming MAX_DISTANCE could change what sd0 returns
+    size_t p = 0;
+    while ((p = cl.find('#', p)) != std::string::npos) {
+        size_t e = cl.find('\n', p);
+        std::string line = cl.substr(p, e == std::string::npos ? std::string::npos : e - p);
+        if (line.find("MAX_DISTANCE") != std::string::npos) return false;
+        if (e == std::string::npos) break;
+        p = e;
+    }
+    return true;
+}
+
+bool scene_cl_is_builtin_only(const std::string& cl)
+{
+    static const char* want[5] = {
+        "returnMAX_DISTANCE;", "return0.0;", "returnlength(v)-0.5;",
+        "v=fabs(v);floatx=length((float2)(v.x,v.z));floaty=v.y;returnmax(x-0.5,y-0.5);",
+        "v=fabs(v);returnmax(v.x-0.5,max(v.y-0.5,v.z-0.5));"};
+    if (cl.find('#') != std::string::npos) return false;  // user defines / AD offsets: compile it
+    for (int n = 0; n < 5; n++)
+        if (brush_body(cl, n) != want[n]) return false;
+    return true;
+}
+
+// ---- exportConfig.txt --------------------------------------------------------------------------
+bool parse_export_config(const char* text, dcsg_export_config& c, std::string& err)
+{
+    if (!text) {
+        err = "export_config_txt is NULL";
+        return false;
+    }
+    // cms::tokenize(contents, '\n') then std::stof / std::stoi per line, DesignCSG.cpp:825-835
+    std::vector<std::string> lines;
+    const char* p = text;
+    while (*p) {
+        const char* e = strchr(p, '\n');
+        size_t len = e ? (size_t)(e - p) : strlen(p);
+        if (len) lines.emplace_back(p, len);
+        if (!e) break;
+        p = e + 1;
+    }
+    if (lines.size() < 9) {
+        err = "exportConfig.txt: expected 9 lines, got " + std::to_string(lines.size());
+        return false;
+    }
+    char* end;
+    auto F = [&](int i, float& o) {
+        o = strtof(lines[i].c_str(), &end);
+        return end != lines[i].c_str();
+    };
+    auto I = [&](int i, int32_t& o) {
+        o = (int32_t)strtol(lines[i].c_str(), &end, 10);
+        return end != lines[i].c_str();
+    };
+    bool ok = F(0, c.bounding_box_half_diameter) && I(1, c.min_level) && I(2, c.max_level) && I(3, c.grid_level) &&
+              F(4, c.complex_surface_threshold) && I(5, c.gradient_descent_steps) && I(6, c.cache_subdivision) &&
+              I(7, c.queries_before_gc) && I(8, c.queries_before_free);
+    if (!ok) err = "exportConfig.txt: malformed number";
+    return ok;
+}
+
+// ---- lookupTable.txt ---------------------------------------------------------------------------
+// getIndexTriangleStrip, geometry.hpp:228-248
+static int triangle_strip(const std::vector<int>& loop, int out[][3])
+{
+    int cnt = 0;
+    size_t first = 0;
+    if (loop.size() % 2 == 1) {
+        out[cnt][0] = loop[0];
+        out[cnt][1] = loop[1];
+        out[cnt][2] = loop.back();
+        cnt++;
+        first = 1;
+    }
+    int m = (int)(loop.size() - first);
+    for (int A = 0; A < m / 2 - 1; A++) {
+        int B = A + 1, D = m - 1 - A, C = D - 1;
+        out[cnt][0] = loop[first + A];
+        out[cnt][1] = loop[first + B];
+        out[cnt][2] = loop[first + C];
+        cnt++;
+        out[cnt][0] = loop[first + C];
+        out[cnt][1] = loop[first + D];
+        out[cnt][2] = loop[first + A];
+        cnt++;
+    }
+    return cnt;
+}
+
+bool parse_lookup_table(const char* text, std::vector<uint8_t>& table, int& total, std::string& err)
+{
+    table.assign(256 * 16, 0);
+    total = 0;
+    int line = 0;
+    const char* p = text;
+    while (*p && line < 256) {
+        const char* e = strchr(p, '\n');
+        size_t len = e ? (size_t)(e - p) : strlen(p);
+        if (len == 0) {  // the tokenizer drops empty lines
+            if (!e) break;
+            p = e + 1;
+            continue;
+        }
+        std::string s(p, len);
+        if (s != "\t") {  // "\t" = case without triangles, readLookupTable.hpp:53
+            size_t i = 0;
+            while (i <= s.size()) {
+                size_t semi = s.find(';', i);
+                std::string cyc = s.substr(i, semi == std::string::npos ? std::string::npos : semi - i);
+                std::vector<int> loop;
+                const char* q = cyc.c_str();
+                while (*q) {
+                    char* end;
+                    long v = strtol(q, &end, 10);
+                    if (end == q) {
+                        q++;
+                        continue;
+                    }
+                    if (v < 0 || v > 11) {
+                        err = "lookup table line " + std::to_string(line) + ": edge id out of range";
+                        return false;
+                    }
+                    loop.push_back((int)v);
+                    q = end;
+                }
+                if (loop.size() >= 3) {
+                    if (loop.size() > 12) {
+                        err = "lookup table line " + std::to_string(line) + ": loop too long";
+                        return false;
+                    }
+                    int st[12][3];
+                    int c = triangle_strip(loop, st);
+                    for (int k = 0; k < c; k++) {
+                        uint8_t& n = table[line * 16];
+                        if (n >= 5) {
+                            err = "lookup table line " + std::to_string(line) + ": more than 5 triangles";
+                            return false;
+                        }
+                        for (int v = 0; v < 3; v++) table[line * 16 + 1 + 3 * n + v] = (uint8_t)st[k][v];
+                        n++;
+                        total++;
+                    }
+                }
+                if (semi == std::string::npos) break;
+                i = semi + 1;
+            }
+        }
+        line++;
+        if (!e) break;
+        p = e + 1;
+    }
+    if (line != 256) {
+        err = "lookup table has " + std::to_string(line) + " cases, expected 256";
+        return false;
+    }
+    return true;
+}
+
+// ---- angle threshold ---------------------------------------------------------------------------
+static int32_t float_to_ordered(float f)
+{
+    int32_t i;
+    memcpy(&i, &f, 4);
+    return i < 0 ? (int32_t)(0x80000000u - (uint32_t)i) : i;
+}
+static float ordered_to_float(int32_t o)
+{
+    int32_t i = o < 0 ? (int32_t)(0x80000000u - (uint32_t)o) : o;
+    float f;
+    memcpy(&f, &i, 4);
+    return f;
+}
+
+float angle_threshold_to_q_star(float threshold)
+{
+    auto over = [&](float q) { return (float)acos((double)q) > threshold; };  // monotone non-increasing in q
+    if (!over(-1.0f)) return -2.0f;
+    if (over(1.0f)) return 1.0f;
+    int32_t lo = float_to_ordered(-1.0f), hi = float_to_ordered(1.0f);  // over(lo) true, over(hi) false
+    while (hi - lo > 1) {
+        int32_t mid = lo + (hi - lo) / 2;
+        if (over(ordered_to_float(mid)))
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return ordered_to_float(lo);
+}
+
+uint64_t fnv1a64(const void* data, size_t n, uint64_t h)
+{
+    const unsigned char* p = (const unsigned char*)data;
+    for (size_t i = 0; i < n; i++) {
+        h ^= p[i];
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+
+}  // namespace dcsg

@@ -1,0 +1,48 @@
+// scene.hpp -- host-side parsing of the compiled scene format (the Python <-> native contract).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/dcsg.h"
+
+namespace dcsg {
+
+// scene.txt + buildprocedure.txt as BasicDrawPane::loadScene reads them (DrawPane.cpp:267-371),
+// validated (the reference has no bounds checks) and packed into
+// the blob the kernels stage into LDS.
+struct Scene {
+    int n_objects = 0, n_steps = 0, n_slots = 0;
+    std::vector<uint8_t> shape;                // [n_objects]
+    std::vector<float> pos, right, up, fwd;    // [3*n_objects]
+    std::vector<int32_t> steps;                // [4*n_steps] opcode,left,right,dest
+    int max_brush_id = 0;                      // over IMPORT steps
+    std::vector<uint32_t> blob;                // uint4-granular, see kernels.hip "Scene tables in LDS"
+    int blob_vec4() const { return (int)(blob.size() / 4); }
+    size_t lds_bytes() const;                  // blob + interpreter stack
+};
+
+bool parse_scene(const char* scene_txt, const char* buildprocedure_txt, Scene& out, std::string& err);
+void build_blob(Scene& s, bool null_brush_is_const);
+
+// True when scene_cl defines sd0..sd4 exactly as the compiler always does
+// (scenecompiler.py:424-425, DesignCSG.py:9-22) and has no preprocessor lines that could change
+// their meaning: then the HIP-native brush bank applies and nothing needs compiling.
+bool scene_cl_is_builtin_only(const std::string& scene_cl);
+// True when sd0's body is `return MAX_DISTANCE;` and MAX_DISTANCE is not redefined.
+bool scene_cl_null_brush_is_const(const std::string& scene_cl);
+
+bool parse_export_config(const char* text, dcsg_export_config& out, std::string& err);
+
+// lookupTable.txt (readLookupTable.hpp:32-76 + getIndexTriangleStrip, geometry.hpp:228-248) expanded to
+// table[case*16] = triangle count, then 3 edge ids per triangle.
+bool parse_lookup_table(const char* text, std::vector<uint8_t>& table, int& total_triangles, std::string& err);
+
+// Largest float q with (float)acos((double)q) > threshold, or -2 if none: folds
+// Vector3f::angleBetweenVectors' acosf (geometry.hpp:118-124) + the comparison of mesh.hpp:253
+// into one device-side compare.
+float angle_threshold_to_q_star(float threshold);
+
+uint64_t fnv1a64(const void* data, size_t n, uint64_t seed);
+
+}  // namespace dcsg

@@ -1,0 +1,64 @@
+/*
+ * scene_prelude.cl -- what the MI355X scene module puts in front of a generated scene.cl.
+ *
+ * The user's brush bodies are OpenCL C text inside the compiled scene format
+ * (scenecompiler.py:476-522); they go through the OpenCL C front-end to gfx950 bitcode
+ * and are linked into the HIP kernels of kernels.hip (csrc/jit.cpp).  This file restates the
+ * environment k2.cl gives them (k2.cl:2,22,29-41: MAX_DISTANCE, getAD, T_min/T_max,
+ * scaleFloat3, the bank prototypes, the program-scope globals) and pins the geometric
+ * built-ins the reference leaves to the OpenCL vendor (k2.cl:111,177; DesignCSG.py:9-22)
+ * as correctly rounded, left-to-right compositions, so that results are reproducible
+ * bit for bit (tests compare with the CPU oracle).  Every other built-in (sin, pow, ...)
+ * resolves to the ROCm device library.
+ */
+#define MAX_DISTANCE 64.0
+#define getAD(name,offset) (arbitrary_data[name+offset])
+#define T_min(a,b) (a<b?a:b)
+#define T_max(a,b) (a>b?a:b)
+
+__global float3 rgt_g;
+__global float3 upp_g;
+__global float3 fwd_g;
+__global float * arbitrary_data;
+
+float3 scaleFloat3(float s, float3 v){ return (float3)(s*v.x,s*v.y,s*v.z); }
+float sdf_bank(float3 v, unsigned char shape_id);
+float3 shader_bank(float3 gv, float3 lv, float3 n, unsigned char material_id);
+
+#define DCSG_OVL __attribute__((overloadable))
+float  DCSG_OVL sqrt(float x){ return __builtin_sqrtf(x); }
+double DCSG_OVL sqrt(double x){ return __builtin_sqrt(x); }
+float  DCSG_OVL fabs(float x){ return __builtin_fabsf(x); }
+double DCSG_OVL fabs(double x){ return __builtin_fabs(x); }
+float2 DCSG_OVL fabs(float2 v){ return (float2)(__builtin_fabsf(v.x),__builtin_fabsf(v.y)); }
+float3 DCSG_OVL fabs(float3 v){ return (float3)(__builtin_fabsf(v.x),__builtin_fabsf(v.y),__builtin_fabsf(v.z)); }
+float4 DCSG_OVL fabs(float4 v){ return (float4)(__builtin_fabsf(v.x),__builtin_fabsf(v.y),__builtin_fabsf(v.z),__builtin_fabsf(v.w)); }
+float  DCSG_OVL dot(float2 a, float2 b){ return a.x*b.x+a.y*b.y; }
+float  DCSG_OVL dot(float3 a, float3 b){ return a.x*b.x+a.y*b.y+a.z*b.z; }
+float  DCSG_OVL dot(float4 a, float4 b){ return a.x*b.x+a.y*b.y+a.z*b.z+a.w*b.w; }
+float  DCSG_OVL length(float a){ return __builtin_fabsf(a); }
+float  DCSG_OVL length(float2 a){ return __builtin_sqrtf(a.x*a.x+a.y*a.y); }
+float  DCSG_OVL length(float3 a){ return __builtin_sqrtf(a.x*a.x+a.y*a.y+a.z*a.z); }
+float  DCSG_OVL length(float4 a){ return __builtin_sqrtf(a.x*a.x+a.y*a.y+a.z*a.z+a.w*a.w); }
+float  DCSG_OVL distance(float3 a, float3 b){ return length(a-b); }
+float3 DCSG_OVL normalize(float3 v){
+    float l = length(v);
+    if (l == 0.0f) return (float3)(0.0f,0.0f,0.0f);
+    return (float3)(v.x/l, v.y/l, v.z/l);
+}
+float  DCSG_OVL max(float x, float y){ return x < y ? y : x; }
+float  DCSG_OVL min(float x, float y){ return y < x ? y : x; }
+double DCSG_OVL max(double x, double y){ return x < y ? y : x; }
+double DCSG_OVL min(double x, double y){ return y < x ? y : x; }
+int    DCSG_OVL max(int x, int y){ return x < y ? y : x; }
+int    DCSG_OVL min(int x, int y){ return y < x ? y : x; }
+float3 DCSG_OVL max(float3 a, float3 b){ return (float3)(max(a.x,b.x),max(a.y,b.y),max(a.z,b.z)); }
+float3 DCSG_OVL min(float3 a, float3 b){ return (float3)(min(a.x,b.x),min(a.y,b.y),min(a.z,b.z)); }
+float3 DCSG_OVL max(float3 a, float b){ return (float3)(max(a.x,b),max(a.y,b),max(a.z,b)); }
+float3 DCSG_OVL min(float3 a, float b){ return (float3)(min(a.x,b),min(a.y,b),min(a.z,b)); }
+float  DCSG_OVL fmax(float x, float y){ return x < y ? y : x; }
+float  DCSG_OVL fmin(float x, float y){ return y < x ? y : x; }
+float  DCSG_OVL clamp(float x, float lo, float hi){ return min(max(x,lo),hi); }
+uint   DCSG_OVL abs(int a){ return (uint)(a < 0 ? -a : a); }
+float  DCSG_OVL floor(float x){ return __builtin_floorf(x); }
+float  DCSG_OVL ceil(float x){ return __builtin_ceilf(x); }

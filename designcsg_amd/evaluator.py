@@ -1,0 +1,200 @@
+"""Host-side mirror of the reference's evaluator / export interface over libdcsg_hip.so.
+
+`Evaluator` keeps the names, argument meaning and error behaviour of the reference class
+(Evaluator.h:20-57, Evaluator.cpp) so that parity tests read like calls into the original:
+
+    ev = Evaluator(device=0)
+    status, log = ev.build(scene_txt, buildprocedure_txt, scene_cl)   # (0, "Success!") / (-1, build log)
+    ev.setArbitraryData(data, items)
+    sdf = ev.eval_sdf_at_points(points)          # n floats
+    nrm = ev.eval_normal_at_points(points)       # n x 3 floats
+
+and adds the export stages the reference runs on the host around it (DesignCSG.cpp:638-790).
+Everything computes on the GPU through the C ABI; numpy is only the container.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import DcsgError, ExportConfig, ExportStats, MeshStats
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f3(v):
+    return (C.c_float * 3)(float(v[0]), float(v[1]), float(v[2]))
+
+
+def read_arbitrary_data(path):
+    """arbitrary_data.hex: 131072 little-endian f32 (updateExportArbitraryData, DesignCSG.cpp:507-529)."""
+    return np.fromfile(path, dtype="<f4")
+
+
+class Evaluator:
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.dcsg_create(C.byref(h), int(device))
+        if rc != 0:
+            raise DcsgError(rc, self._L.dcsg_last_error(None).decode(errors="replace"))
+        self._h = h
+        self.build_success = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dcsg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        return _lib.check(self._h, rc)
+
+    # ---- Evaluator::build (Evaluator.cpp:45-112) -------------------------------------------
+    def build(self, scene_txt, buildprocedure_txt, scene_cl=None, arbitrary_data=None):
+        ad = None
+        n_ad = 0
+        if arbitrary_data is not None:
+            ad = np.ascontiguousarray(arbitrary_data, dtype=np.float32)
+            n_ad = ad.size
+        rc = self._L.dcsg_load_scene(self._h, scene_txt.encode(), buildprocedure_txt.encode(),
+                                     None if scene_cl is None else scene_cl.encode(),
+                                     None if ad is None else _fptr(ad), n_ad)
+        if rc == _lib.ERR_BUILD:
+            self.build_success = 0
+            return -1, self._L.dcsg_last_error(self._h).decode(errors="replace")
+        self._ck(rc)
+        self.build_success = 1
+        return 0, "Success!"
+
+    def build_from_dir(self, scene_dir, use_scene_cl=True):
+        """Load the files a design run leaves in its working directory."""
+        rd = lambda n: open(os.path.join(scene_dir, n)).read()
+        scl = rd("scene.cl") if use_scene_cl and os.path.exists(os.path.join(scene_dir, "scene.cl")) else None
+        adp = os.path.join(scene_dir, "arbitrary_data.hex")
+        ad = read_arbitrary_data(adp) if os.path.exists(adp) else None
+        return self.build(rd("scene.txt"), rd("buildprocedure.txt"), scl, ad)
+
+    def scene_info(self):
+        v = [C.c_int() for _ in range(4)]
+        self._ck(self._L.dcsg_scene_info(self._h, *[C.byref(x) for x in v]))
+        return dict(objects=v[0].value, steps=v[1].value, slots=v[2].value, jit=bool(v[3].value))
+
+    # ---- Evaluator::setArbitraryData (Evaluator.cpp:213-225) ------------------------------
+    def setArbitraryData(self, data, items=None):
+        a = np.ascontiguousarray(data, dtype=np.float32)
+        self._ck(self._L.dcsg_set_arbitrary_data(self._h, _fptr(a), a.size if items is None else int(items)))
+
+    # ---- Evaluator::eval_*_at_points (Evaluator.cpp:117-211) -------------------------------
+    def eval_sdf_at_points(self, points):
+        p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        out = np.empty(len(p), dtype=np.float32)
+        self._ck(self._L.dcsg_eval_sdf(self._h, _fptr(p), len(p), _fptr(out)))
+        return out
+
+    def eval_normal_at_points(self, points):
+        p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        out = np.empty((len(p), 3), dtype=np.float32)
+        self._ck(self._L.dcsg_eval_normal(self._h, _fptr(p), len(p), _fptr(out)))
+        return out
+
+    # ---- dense lattice (ISV.hpp) -------------------------------------------------------------
+    def eval_lattice(self, center, diameter, res, z0=0, z1=None, sdf=True, normals=True):
+        n1 = res + 1
+        z1 = n1 if z1 is None else z1
+        d = [diameter] * 3 if np.isscalar(diameter) else diameter
+        s = np.empty((z1 - z0, n1, n1), dtype=np.float32) if sdf else None
+        n = np.empty((z1 - z0, n1, n1, 3), dtype=np.float32) if normals else None
+        self._ck(self._L.dcsg_eval_lattice(self._h, _f3(center), _f3(d), res, z0, z1,
+                                           _fptr(s) if sdf else None, _fptr(n) if normals else None))
+        return s, n
+
+    def sweep_lattice_device(self, center, diameter, res, z0, z1, d_sdf, d_normals, stream=0):
+        """Device-pointer sweep (torch tensors' data_ptr()); asynchronous on `stream`."""
+        d = [diameter] * 3 if np.isscalar(diameter) else diameter
+        self._ck(self._L.dcsg_sweep_lattice_device(self._h, _f3(center), _f3(d), res, z0, z1,
+                                                   C.c_void_p(d_sdf or None), C.c_void_p(d_normals or None),
+                                                   C.c_void_p(stream or None)))
+
+    def last_sweep_ms(self):
+        ms = C.c_double()
+        self._ck(self._L.dcsg_last_sweep_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    # ---- export stages (DesignCSG.cpp:638-790) ------------------------------------------------
+    def estimate_bounding_box(self, bounding_box_half_diameter):
+        c = (C.c_float * 3)()
+        d = C.c_float()
+        n = C.c_uint64()
+        self._ck(self._L.dcsg_estimate_bounding_box(self._h, bounding_box_half_diameter, c, C.byref(d), C.byref(n)))
+        return [c[0], c[1], c[2]], d.value, n.value
+
+    def set_lookup_table(self, text):
+        self._ck(self._L.dcsg_set_lookup_table(self._h, text.encode()))
+
+    def mesh_lattice_device(self, center, diameter, cfg, d_sdf, d_normals, z_lo, z_hi, z_own_lo, z_own_hi,
+                            stream=0):
+        n = C.c_uint64()
+        st = MeshStats()
+        self._ck(self._L.dcsg_mesh_lattice_device(self._h, _f3(center), diameter, C.byref(cfg),
+                                                  C.c_void_p(d_sdf or None), C.c_void_p(d_normals or None),
+                                                  z_lo, z_hi, z_own_lo, z_own_hi, C.byref(n), C.byref(st),
+                                                  C.c_void_p(stream or None)))
+        return n.value, st
+
+    def project_triangles(self, steps, stream=0):
+        self._ck(self._L.dcsg_project_triangles(self._h, steps, C.c_void_p(stream or None)))
+
+    def project_vertices_device(self, d_xyz, n_vertices, steps, stream=0):
+        self._ck(self._L.dcsg_project_vertices_device(self._h, C.c_void_p(d_xyz), n_vertices, steps,
+                                                      C.c_void_p(stream or None)))
+
+    def triangles_device(self):
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._ck(self._L.dcsg_triangles_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def download_triangles(self):
+        _, n = self.triangles_device()
+        out = np.empty((n, 3, 3), dtype=np.float32)
+        self._ck(self._L.dcsg_download_triangles(self._h, _fptr(out), n))
+        return out
+
+    def export(self, export_config_txt, stl_path=None, ply_path=None, dense_normals=False):
+        """MyFrame::OnExportInner end to end on this GPU."""
+        st = ExportStats()
+        self._ck(self._L.dcsg_export(self._h, export_config_txt.encode(),
+                                     None if stl_path is None else os.fsencode(stl_path),
+                                     None if ply_path is None else os.fsencode(ply_path),
+                                     _lib.EXPORT_DENSE_NORMALS if dense_normals else 0, C.byref(st)))
+        return st
+
+
+def parse_export_config(text):
+    cfg = ExportConfig()
+    if _lib.lib().dcsg_parse_export_config(text.encode(), C.byref(cfg)) != 0:
+        raise ValueError("malformed exportConfig.txt")
+    return cfg
+
+
+def write_stl(path, tris):
+    t = np.ascontiguousarray(tris, dtype=np.float32)
+    rc = _lib.lib().dcsg_write_stl(os.fsencode(path), _fptr(t), t.size // 9)
+    if rc:
+        raise DcsgError(rc, "cannot write " + str(path))
+
+
+def write_ply(path, tris):
+    t = np.ascontiguousarray(tris, dtype=np.float32)
+    rc = _lib.lib().dcsg_write_ply(os.fsencode(path), _fptr(t), t.size // 9)
+    if rc:
+        raise DcsgError(rc, "cannot write " + str(path))

@@ -1,0 +1,159 @@
+/*
+ * dcsg.h -- C ABI of libdcsg_hip.so: the MI355X-native export path of DesignCSG.
+ *
+ * Drop-in boundary.  The reference has no FFI; its export path sits behind
+ *   (1) the compiled scene files written by the Python design API
+ *       (scene.txt, buildprocedure.txt, scene.cl, arbitrary_data.hex, exportConfig.txt;
+ *        scenecompiler.py:466-582, DesignCSG.py:205-237), and
+ *   (2) class Evaluator (Evaluator.h:20-57), which the GUI's export thread
+ *       (DesignCSG.cpp:638-790, OnExportInner) drives.
+ * Each entry point below names the reference interface it replaces
+ * (paths relative to /root/reference/master).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative dcsg_status and records a message retrievable with dcsg_last_error().  "host"
+ * pointers are ordinary memory; "_device" entry points take HIP device pointers (e.g.
+ * torch tensor data_ptr()) and a hipStream_t passed as void*, and do not synchronise.
+ * A context is bound to one GPU and is not re-entrant (the reference serialises every
+ * evaluator call behind one global mutex, Evaluator.cpp:10,120,170); use one context per
+ * thread or lock around it.
+ */
+#ifndef DCSG_H
+#define DCSG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCSG_ARBITRARY_DATA_POINTS 131072 /* Evaluator.h:17 */
+#define DCSG_MAX_LEVELS 16
+
+typedef struct dcsg_ctx dcsg_ctx;
+
+typedef enum dcsg_status {
+    DCSG_OK = 0,
+    DCSG_ERR_INVALID = -1,   /* bad argument / malformed scene file */
+    DCSG_ERR_NO_DEVICE = -2, /* no usable HIP device: there is no CPU fallback */
+    DCSG_ERR_HIP = -3,       /* HIP runtime error */
+    DCSG_ERR_BUILD = -4,     /* scene.cl failed to compile; log in dcsg_last_error (Evaluator.cpp:64-89) */
+    DCSG_ERR_NO_SCENE = -5,  /* evaluation before dcsg_load_scene ("Cannot Export Yet.", DesignCSG.cpp:786) */
+    DCSG_ERR_IO = -6
+} dcsg_status;
+
+/* exportConfig.txt, parsed positionally like DesignCSG.cpp:827-835 */
+typedef struct dcsg_export_config {
+    float bounding_box_half_diameter; /* already multiplied by 5 by setExportConfig (DesignCSG.py:225) */
+    int32_t min_level, max_level, grid_level;
+    float complex_surface_threshold;  /* radians */
+    int32_t gradient_descent_steps;
+    int32_t cache_subdivision, queries_before_gc, queries_before_free; /* accepted, unused: no ISV cache */
+} dcsg_export_config;
+
+typedef struct dcsg_mesh_stats {
+    uint64_t nodes[DCSG_MAX_LEVELS];      /* nodes visited per octree level */
+    uint64_t culled[DCSG_MAX_LEVELS];     /* mesh.hpp:170 */
+    uint64_t subdivided[DCSG_MAX_LEVELS];
+    uint64_t leaves[DCSG_MAX_LEVELS];
+    uint64_t triangles[DCSG_MAX_LEVELS];  /* emitted by leaves of that level */
+} dcsg_mesh_stats;
+
+typedef struct dcsg_export_stats {
+    float box_center[3];
+    float box_diameter;
+    uint64_t interior_points;  /* stage A: samples with sdf < bbHalf/256 */
+    uint64_t lattice_points;   /* (res+1)^3 */
+    uint64_t triangles;
+    dcsg_mesh_stats mesh;
+    /* wall-clock seconds per stage (host clock, device synchronised at stage ends) */
+    double t_bbox, t_sweep, t_mesh, t_project, t_download, t_write_stl, t_write_ply, t_total;
+    /* device time of the lattice sweep kernel(s), milliseconds (HIP events) */
+    double sweep_kernel_ms;
+} dcsg_export_stats;
+
+/* ---- life cycle ------------------------------------------------------------------- */
+/* Evaluator::Evaluator (Evaluator.cpp:14-40): binds a device, creates staging buffers. */
+int dcsg_create(dcsg_ctx** out, int device_id);
+void dcsg_destroy(dcsg_ctx* ctx);
+/* Message of the last failure on ctx (or of dcsg_create when ctx is NULL). */
+const char* dcsg_last_error(const dcsg_ctx* ctx);
+
+/* ---- scene ------------------------------------------------------------------------ */
+/* BasicDrawPane::loadScene parsing (DrawPane.cpp:267-371) + Evaluator::build
+ * (Evaluator.cpp:45-112: clBuildProgram of k2.cl+scene.cl) + setArbitraryData.
+ * scene_cl may be NULL when every brush id in scene.txt is one of the five built-ins 0..4.
+ * arbitrary_data may be NULL (all zeros); n_arbitrary <= DCSG_ARBITRARY_DATA_POINTS.
+ * On a brush compile error returns DCSG_ERR_BUILD with the compiler log as the error string,
+ * like Evaluator::build returning (-1, log). */
+int dcsg_load_scene(dcsg_ctx* ctx, const char* scene_txt, const char* buildprocedure_txt, const char* scene_cl,
+                    const float* arbitrary_data, size_t n_arbitrary);
+/* Evaluator::setArbitraryData (Evaluator.cpp:213-225): copies `items` floats, uploads the whole table. */
+int dcsg_set_arbitrary_data(dcsg_ctx* ctx, const float* data, size_t items);
+/* Scene facts after loading: counts and interpreter stack slots in use. */
+int dcsg_scene_info(const dcsg_ctx* ctx, int* n_objects, int* n_steps, int* n_slots, int* jit_compiled);
+
+/* ---- point evaluation = kernel k2 (k2.cl:234-280) ---------------------------------- */
+/* Evaluator::eval_sdf_at_points (Evaluator.cpp:117-165): xyz = n x 3 floats, out = n floats. */
+int dcsg_eval_sdf(dcsg_ctx* ctx, const float* xyz, size_t n, float* out);
+/* Evaluator::eval_normal_at_points (Evaluator.cpp:167-211): out_xyz = n x 3 floats. */
+int dcsg_eval_normal(dcsg_ctx* ctx, const float* xyz, size_t n, float* out_xyz);
+int dcsg_eval_sdf_device(dcsg_ctx* ctx, const float* d_xyz, size_t n, float* d_out, void* stream);
+int dcsg_eval_normal_device(dcsg_ctx* ctx, const float* d_xyz, size_t n, float* d_out_xyz, void* stream);
+
+/* ---- dense lattice = ISV3D64 (ISV.hpp:8-138) evaluated everywhere, once ------------- */
+/* Fused SDF + central-difference-normal sweep of lattice planes z in [z0,z1) of the (res+1)^3
+ * lattice over box{center,diameters} (ISV.hpp:103-109), x fastest.  d_sdf: (z1-z0)*(res+1)^2
+ * floats or NULL; d_normals: 3x that (AoS xyz) or NULL. */
+int dcsg_sweep_lattice_device(dcsg_ctx* ctx, const float center[3], const float diameters[3], int res, int z0, int z1,
+                              float* d_sdf, float* d_normals, void* stream);
+/* Same with host outputs (allocates, sweeps, copies back). */
+int dcsg_eval_lattice(dcsg_ctx* ctx, const float center[3], const float diameters[3], int res, int z0, int z1,
+                      float* sdf, float* normals);
+
+/* ---- export stages (DesignCSG.cpp:638-790) ------------------------------------------ */
+/* Stage A (DesignCSG.cpp:668-712): 256^3 probe, cube = max extent, always contains the origin. */
+int dcsg_estimate_bounding_box(dcsg_ctx* ctx, float bounding_box_half_diameter, float center[3], float* diameter,
+                               uint64_t* interior_points);
+/* cms::getIndexTrianglesFromTable (readLookupTable.hpp:32-76): replaces the packaged table. */
+int dcsg_set_lookup_table(dcsg_ctx* ctx, const char* lookup_table_txt);
+/* cms::Mesh::getSurface (mesh.hpp:82-389) over resident lattice planes z_lo..z_hi (inclusive) held in
+ * d_sdf (and d_normals, or NULL to evaluate normals on demand).  Nodes are restricted to the Z-slab
+ * [z_own_lo, z_own_hi) (0,res for the whole box).  Triangles (9 floats each: A,B,C xyz) stay in a
+ * context-owned device buffer; *n_triangles receives the count.  stats may be NULL. */
+int dcsg_mesh_lattice_device(dcsg_ctx* ctx, const float center[3], float diameter, const dcsg_export_config* cfg,
+                             const float* d_sdf, const float* d_normals, int z_lo, int z_hi, int z_own_lo,
+                             int z_own_hi, uint64_t* n_triangles, dcsg_mesh_stats* stats, void* stream);
+/* cms::performGradientDescent (mesh.hpp:531-593) on the context's triangle buffer, in place. */
+int dcsg_project_triangles(dcsg_ctx* ctx, int steps, void* stream);
+/* Same on caller-owned device vertices (n_vertices x 3 floats). */
+int dcsg_project_vertices_device(dcsg_ctx* ctx, float* d_xyz, size_t n_vertices, int steps, void* stream);
+/* Device pointer / host copy of the context's triangle buffer. */
+int dcsg_triangles_device(dcsg_ctx* ctx, const float** d_triangles, uint64_t* n_triangles);
+int dcsg_download_triangles(dcsg_ctx* ctx, float* out, uint64_t max_triangles);
+
+/* cms::writeTrianglesToSTL (utils.hpp:41-103) / writeTrianglesToPLY (utils.hpp:106-154). */
+int dcsg_write_stl(const char* path, const float* triangles, uint64_t n_triangles);
+int dcsg_write_ply(const char* path, const float* triangles, uint64_t n_triangles);
+
+int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* out);
+/* MyFrame::OnExportInner (DesignCSG.cpp:638-790) end to end on one GPU: stage A, lattice sweep,
+ * mesher, retopologize (identity), projection, both writers.
+ * stl_path / ply_path may be NULL to skip a writer.  flags: DCSG_EXPORT_*. */
+#define DCSG_EXPORT_DENSE_NORMALS 1u /* sweep normals for every lattice point instead of on demand */
+int dcsg_export(dcsg_ctx* ctx, const char* export_config_txt, const char* stl_path, const char* ply_path,
+                unsigned flags, dcsg_export_stats* stats);
+
+/* Device time in ms of the most recent lattice sweep (HIP events on its stream; synchronises). */
+int dcsg_last_sweep_ms(dcsg_ctx* ctx, double* ms);
+
+/* The compile half of Evaluator::build without a device: compiles scene_cl into the on-disk code
+ * object cache (used at install time so that known scenes load without compiling).  The compiler
+ * log is copied to log_out; *from_cache = 1 when the code object already existed. */
+int dcsg_jit_prebuild(const char* scene_cl, char* log_out, size_t log_cap, int* from_cache);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
