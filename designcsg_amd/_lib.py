@@ -92,6 +92,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(designcsg_amd has no CPU fallback)" % LIB_PATH)
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64 / libhsa-runtime64 under the
+        # same SONAMEs as /opt/rocm.  Importing torch first makes libdcsg_hip bind to that copy, so that
+        # torch tensors, streams and RCCL share one runtime with our kernels.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)

@@ -11,7 +11,7 @@
 // Code objects are cached on disk keyed by a hash of every input.
 #include "jit.hpp"
 
-#include <amd_comgr/amd_comgr.h>
+#include <amd_comgr/amd_comgr.h>  // types and enums only: the library itself is dlopen'ed, see comgr()
 #include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -20,6 +20,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <vector>
 
 #include "scene.hpp"
 
@@ -28,6 +29,77 @@ namespace dcsg {
 #include "embedded_cl.inc"  // kScenePrelude / kSceneEpilogue, generated from the .cl files by build.py
 
 static const char* kIsa = "amdgcn-amd-amdhsa--gfx950";
+
+// libamd_comgr is loaded by absolute path from the ROCm installation whose compiler produced
+// dcsg_kernels_extern.bc, with RTLD_LOCAL | RTLD_DEEPBIND.  A PyTorch process already holds a
+// bundled libamd_comgr.so.3 (older LLVM, same SONAME) that cannot read this bitcode, so linking
+// against the SONAME would silently pick the wrong one.
+struct ComgrApi {
+    void* handle = nullptr;
+    std::string error;
+#define DCSG_COMGR_FN(name) decltype(&::name) name = nullptr;
+    DCSG_COMGR_FN(amd_comgr_create_data)
+    DCSG_COMGR_FN(amd_comgr_release_data)
+    DCSG_COMGR_FN(amd_comgr_set_data)
+    DCSG_COMGR_FN(amd_comgr_set_data_name)
+    DCSG_COMGR_FN(amd_comgr_get_data)
+    DCSG_COMGR_FN(amd_comgr_create_data_set)
+    DCSG_COMGR_FN(amd_comgr_destroy_data_set)
+    DCSG_COMGR_FN(amd_comgr_data_set_add)
+    DCSG_COMGR_FN(amd_comgr_action_data_count)
+    DCSG_COMGR_FN(amd_comgr_action_data_get_data)
+    DCSG_COMGR_FN(amd_comgr_create_action_info)
+    DCSG_COMGR_FN(amd_comgr_destroy_action_info)
+    DCSG_COMGR_FN(amd_comgr_action_info_set_isa_name)
+    DCSG_COMGR_FN(amd_comgr_action_info_set_language)
+    DCSG_COMGR_FN(amd_comgr_action_info_set_option_list)
+    DCSG_COMGR_FN(amd_comgr_action_info_set_logging)
+    DCSG_COMGR_FN(amd_comgr_do_action)
+    DCSG_COMGR_FN(amd_comgr_status_string)
+#undef DCSG_COMGR_FN
+};
+
+static ComgrApi& comgr()
+{
+    static ComgrApi api;
+    if (api.handle || !api.error.empty()) return api;
+    std::vector<std::string> candidates;
+    if (const char* e = getenv("DCSG_COMGR_PATH")) candidates.push_back(e);
+    const char* rocm = getenv("ROCM_PATH");
+    candidates.push_back(std::string(rocm ? rocm : "/opt/rocm") + "/lib/libamd_comgr.so.3");
+    candidates.push_back("/opt/rocm/lib/libamd_comgr.so.3");
+    candidates.push_back("libamd_comgr.so.3");
+    for (auto& c : candidates) {
+        api.handle = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+        if (api.handle) break;
+        api.error += std::string(dlerror()) + "\n";
+    }
+    if (!api.handle) return api;
+    api.error.clear();
+#define DCSG_COMGR_FN(name)                                           \
+    api.name = (decltype(api.name))dlsym(api.handle, #name);          \
+    if (!api.name) api.error += "libamd_comgr lacks " #name "\n";
+    DCSG_COMGR_FN(amd_comgr_create_data)
+    DCSG_COMGR_FN(amd_comgr_release_data)
+    DCSG_COMGR_FN(amd_comgr_set_data)
+    DCSG_COMGR_FN(amd_comgr_set_data_name)
+    DCSG_COMGR_FN(amd_comgr_get_data)
+    DCSG_COMGR_FN(amd_comgr_create_data_set)
+    DCSG_COMGR_FN(amd_comgr_destroy_data_set)
+    DCSG_COMGR_FN(amd_comgr_data_set_add)
+    DCSG_COMGR_FN(amd_comgr_action_data_count)
+    DCSG_COMGR_FN(amd_comgr_action_data_get_data)
+    DCSG_COMGR_FN(amd_comgr_create_action_info)
+    DCSG_COMGR_FN(amd_comgr_destroy_action_info)
+    DCSG_COMGR_FN(amd_comgr_action_info_set_isa_name)
+    DCSG_COMGR_FN(amd_comgr_action_info_set_language)
+    DCSG_COMGR_FN(amd_comgr_action_info_set_option_list)
+    DCSG_COMGR_FN(amd_comgr_action_info_set_logging)
+    DCSG_COMGR_FN(amd_comgr_do_action)
+    DCSG_COMGR_FN(amd_comgr_status_string)
+#undef DCSG_COMGR_FN
+    return api;
+}
 
 std::string library_dir()
 {
@@ -77,21 +149,21 @@ static std::string cache_dir()
 struct ComgrSet {
     amd_comgr_data_set_t s{};
     bool ok = false;
-    ComgrSet() { ok = amd_comgr_create_data_set(&s) == AMD_COMGR_STATUS_SUCCESS; }
+    ComgrSet() { ok = comgr().amd_comgr_create_data_set(&s) == AMD_COMGR_STATUS_SUCCESS; }
     ~ComgrSet()
     {
-        if (ok) amd_comgr_destroy_data_set(s);
+        if (ok) comgr().amd_comgr_destroy_data_set(s);
     }
 };
 
 static bool add_data(amd_comgr_data_set_t set, amd_comgr_data_kind_t kind, const char* name, const std::string& bytes)
 {
     amd_comgr_data_t d;
-    if (amd_comgr_create_data(kind, &d) != AMD_COMGR_STATUS_SUCCESS) return false;
-    bool ok = amd_comgr_set_data(d, bytes.size(), bytes.data()) == AMD_COMGR_STATUS_SUCCESS &&
-              amd_comgr_set_data_name(d, name) == AMD_COMGR_STATUS_SUCCESS &&
-              amd_comgr_data_set_add(set, d) == AMD_COMGR_STATUS_SUCCESS;
-    amd_comgr_release_data(d);
+    if (comgr().amd_comgr_create_data(kind, &d) != AMD_COMGR_STATUS_SUCCESS) return false;
+    bool ok = comgr().amd_comgr_set_data(d, bytes.size(), bytes.data()) == AMD_COMGR_STATUS_SUCCESS &&
+              comgr().amd_comgr_set_data_name(d, name) == AMD_COMGR_STATUS_SUCCESS &&
+              comgr().amd_comgr_data_set_add(set, d) == AMD_COMGR_STATUS_SUCCESS;
+    comgr().amd_comgr_release_data(d);
     return ok;
 }
 
@@ -99,17 +171,17 @@ static std::string collect(amd_comgr_data_set_t set, amd_comgr_data_kind_t kind)
 {
     std::string out;
     size_t n = 0;
-    if (amd_comgr_action_data_count(set, kind, &n) != AMD_COMGR_STATUS_SUCCESS) return out;
+    if (comgr().amd_comgr_action_data_count(set, kind, &n) != AMD_COMGR_STATUS_SUCCESS) return out;
     for (size_t i = 0; i < n; i++) {
         amd_comgr_data_t d;
-        if (amd_comgr_action_data_get_data(set, kind, i, &d) != AMD_COMGR_STATUS_SUCCESS) continue;
+        if (comgr().amd_comgr_action_data_get_data(set, kind, i, &d) != AMD_COMGR_STATUS_SUCCESS) continue;
         size_t sz = 0;
-        if (amd_comgr_get_data(d, &sz, nullptr) == AMD_COMGR_STATUS_SUCCESS && sz) {
+        if (comgr().amd_comgr_get_data(d, &sz, nullptr) == AMD_COMGR_STATUS_SUCCESS && sz) {
             std::string b(sz, '\0');
-            amd_comgr_get_data(d, &sz, &b[0]);
+            comgr().amd_comgr_get_data(d, &sz, &b[0]);
             out += b;
         }
-        amd_comgr_release_data(d);
+        comgr().amd_comgr_release_data(d);
     }
     return out;
 }
@@ -118,24 +190,24 @@ static bool run_action(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, 
                        amd_comgr_data_set_t in, amd_comgr_data_set_t out, std::string& log)
 {
     amd_comgr_action_info_t info;
-    if (amd_comgr_create_action_info(&info) != AMD_COMGR_STATUS_SUCCESS) {
+    if (comgr().amd_comgr_create_action_info(&info) != AMD_COMGR_STATUS_SUCCESS) {
         log += "comgr: create_action_info failed\n";
         return false;
     }
-    bool ok = amd_comgr_action_info_set_isa_name(info, kIsa) == AMD_COMGR_STATUS_SUCCESS;
+    bool ok = comgr().amd_comgr_action_info_set_isa_name(info, kIsa) == AMD_COMGR_STATUS_SUCCESS;
     if (ok && lang != AMD_COMGR_LANGUAGE_NONE)
-        ok = amd_comgr_action_info_set_language(info, lang) == AMD_COMGR_STATUS_SUCCESS;
+        ok = comgr().amd_comgr_action_info_set_language(info, lang) == AMD_COMGR_STATUS_SUCCESS;
     if (ok && !opts.empty())
-        ok = amd_comgr_action_info_set_option_list(info, const_cast<const char**>(opts.data()), opts.size()) ==
+        ok = comgr().amd_comgr_action_info_set_option_list(info, const_cast<const char**>(opts.data()), opts.size()) ==
              AMD_COMGR_STATUS_SUCCESS;
-    if (ok) ok = amd_comgr_action_info_set_logging(info, true) == AMD_COMGR_STATUS_SUCCESS;
+    if (ok) ok = comgr().amd_comgr_action_info_set_logging(info, true) == AMD_COMGR_STATUS_SUCCESS;
     amd_comgr_status_t st = AMD_COMGR_STATUS_ERROR;
-    if (ok) st = amd_comgr_do_action(kind, info, in, out);
-    amd_comgr_destroy_action_info(info);
+    if (ok) st = comgr().amd_comgr_do_action(kind, info, in, out);
+    comgr().amd_comgr_destroy_action_info(info);
     std::string l = collect(out, AMD_COMGR_DATA_KIND_LOG);
     if (st != AMD_COMGR_STATUS_SUCCESS) {
         const char* name = nullptr;
-        amd_comgr_status_string(st, &name);
+        comgr().amd_comgr_status_string(st, &name);
         log += l;
         log += std::string("comgr action ") + std::to_string((int)kind) + " failed: " + (name ? name : "?") + "\n";
         return false;
@@ -166,6 +238,10 @@ bool jit_scene_module(const std::string& scene_cl, std::string& hsaco, std::stri
         return true;
     }
 
+    if (!comgr().handle || !comgr().error.empty()) {
+        log = "cannot load the ROCm code object manager (libamd_comgr.so.3):\n" + comgr().error;
+        return false;
+    }
     // 1. brush text (OpenCL C) -> gfx950 bitcode.  No contraction, IEEE divide/sqrt: the numerics
     //    contract of kernels.hip.  "-w" as in the reference's build options (Utils.cpp:78-81).
     ComgrSet src, bc;
