@@ -36,18 +36,32 @@ WORKLOADS = {
 }
 
 
+def host_cores():
+    """Threads this job may actually use: the cgroup CPU quota if there is one, else the affinity
+    mask, capped at the GPU box's per-GPU CPU share (16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("DCSG_CPU_THREADS", "16")))
+
+
 def cpu_baseline(scene_dir, center, diameter, res, budget_s=15.0):
     """The oracle (own CPU restatement, kind "port") timed on this host's cores on a bounded sample
     of the same workload: whole lattice planes around the middle of the box."""
     from oracle import oracle as O
     O.build()
     osc = O.Scene.from_dir(scene_dir)
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     n1 = res + 1
     z = n1 // 2
+    osc.eval_lattice(center, diameter, res, z, z + 1, threads=cores)  # warm up the thread pool, untimed
     t0 = time.perf_counter()
-    osc.eval_lattice(center, diameter, res, z, z + 1, threads=cores)
-    t1 = time.perf_counter() - t0
+    osc.eval_lattice(center, diameter, res, z, z + 2, threads=cores)
+    t1 = (time.perf_counter() - t0) / 2
     planes = max(1, min(n1 - z, int(budget_s / max(t1, 1e-4))))
     t0 = time.perf_counter()
     osc.eval_lattice(center, diameter, res, z, z + planes, threads=cores)

@@ -48,7 +48,7 @@ PROTOTYPES = {
     "dcsg_last_error": (C.c_char_p, [C.c_void_p]),
     "dcsg_load_scene": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "dcsg_set_arbitrary_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
-    "dcsg_scene_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 4),
+    "dcsg_scene_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 6),
     "dcsg_eval_sdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dcsg_eval_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dcsg_eval_sdf_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -28,9 +28,11 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// Interpreter variants of the evaluation kernels (kernels.hip): [0] generic (register program, stack in
+// LDS, any program), [1] / [2] stack program with a register-resident stack of depth <= 4 / <= 8.
 struct Kernels {
-    hipFunction_t sweep = nullptr, eval_points = nullptr, bbox = nullptr, classify = nullptr, scan = nullptr,
-                  emit = nullptr, project = nullptr, set_ad = nullptr;
+    hipFunction_t sweep[3] = {}, eval_points[3] = {}, bbox[3] = {}, project[3] = {};
+    hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr;
 };
 
 double now_s()
@@ -51,6 +53,7 @@ struct dcsg_ctx {
     Kernels kb, ks;       // built-in bank / scene module
     Kernels* k = nullptr;  // active
     bool scene_loaded = false, jit = false;
+    int variant = 0;  // index into Kernels::sweep[] etc., chosen from the scene's register count
     Scene scene;
     std::vector<float> ad_host;
     std::vector<uint8_t> tri_table;
@@ -112,12 +115,19 @@ void release(DevBuf& b)
 
 int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
 {
+    static const char* suffix[3] = {"", "_s4", "_s8"};
+    for (int v = 0; v < 3; v++) {
+        struct {
+            const char* name;
+            hipFunction_t* f;
+        } tab[] = {{"dcsg_sweep", &k.sweep[v]}, {"dcsg_eval_points", &k.eval_points[v]}, {"dcsg_bbox", &k.bbox[v]},
+                   {"dcsg_project", &k.project[v]}};
+        for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, (std::string(t.name) + suffix[v]).c_str()));
+    }
     struct {
         const char* name;
         hipFunction_t* f;
-    } tab[] = {{"dcsg_sweep", &k.sweep},         {"dcsg_eval_points", &k.eval_points}, {"dcsg_bbox", &k.bbox},
-               {"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan},      {"dcsg_mesh_emit", &k.emit},
-               {"dcsg_project", &k.project}};
+    } tab[] = {{"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan}, {"dcsg_mesh_emit", &k.emit}};
     for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
     if (scene_module) HIPCHK(c, hipModuleGetFunction(&k.set_ad, mod, "dcsg_set_arbitrary_data"));
     return 0;
@@ -145,6 +155,11 @@ DcsgLattice make_lattice(const float center[3], const float diam[3], int res)
     L.inv_w = 1.0f / (float)res;
     L.res = res;
     L.w_pow2 = (res > 0 && (res & (res - 1)) == 0) ? 1 : 0;
+    // n / (res+1) by multiply-high, round-up method: exact for every 32-bit n
+    uint32_t d = (uint32_t)res + 1u, lg = 0;
+    while ((1ull << lg) < d) lg++;
+    L.n1_magic = (unsigned)((((1ull << lg) - d) << 32) / d + 1);
+    L.n1_shift = lg ? lg - 1 : 0;
     return L;
 }
 
@@ -174,7 +189,7 @@ int eval_points_device(dcsg_ctx* c, const float* d_xyz, size_t n, int mode, floa
         float* out = d_out + off * (mode == 0 ? 1 : 3);
         unsigned tiles = (cnt + DCSG_BLOCK - 1) / DCSG_BLOCK;
         void* args[] = {(void*)&blob, &nv, (void*)&in, &cnt, &mode, (void*)&out};
-        int r = launch(c, c->k->eval_points, sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), s, args);
+        int r = launch(c, c->k->eval_points[c->variant], sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), s, args);
         if (r) return r;
     }
     return 0;
@@ -220,7 +235,7 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
         unsigned cnt = (unsigned)((total - first64) < chunk ? (total - first64) : chunk);
         unsigned tiles = (cnt + DCSG_BLOCK - 1) / DCSG_BLOCK;
         void* args[] = {(void*)&blob, &nv, &L, &z0, &first, &cnt, (void*)&d_sdf, (void*)&d_nrm};
-        int r = launch(c, c->k->sweep, sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), s, args);
+        int r = launch(c, c->k->sweep[c->variant], sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), s, args);
         if (r) return r;
     }
     if (time_it) {
@@ -390,19 +405,28 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     if (r) return r;
     HIPCHK(c, hipMemcpy(c->d_blob.p, s.blob.data(), s.blob.size() * 4, hipMemcpyHostToDevice));
     c->scene = std::move(s);
+    const int depth = c->scene.n_stack_prog ? c->scene.stack_depth : 1000;
+    c->variant = depth <= 4 ? 1 : (depth <= 8 ? 2 : 0);
+    if (const char* force = getenv("DCSG_FORCE_VARIANT")) {  // A/B testing only; never exceeds what the program fits
+        int f = atoi(force);
+        if (f == 0 || (f == 2 && depth <= 8)) c->variant = f;
+    }
     c->scene_loaded = true;
     c->n_tris = 0;
     std::fill(c->ad_host.begin(), c->ad_host.end(), 0.0f);
     return dcsg_set_arbitrary_data(c, ad, ad ? n_ad : 0);
 }
 
-int dcsg_scene_info(const dcsg_ctx* c, int* n_objects, int* n_steps, int* n_slots, int* jit_compiled)
+int dcsg_scene_info(const dcsg_ctx* c, int* n_objects, int* n_steps, int* n_slots, int* jit_compiled, int* interpreter,
+                    int* stack_depth)
 {
     if (!c || !c->scene_loaded) return DCSG_ERR_NO_SCENE;
     if (n_objects) *n_objects = c->scene.n_objects;
     if (n_steps) *n_steps = c->scene.n_steps;
-    if (n_slots) *n_slots = c->scene.n_slots;
+    if (n_slots) *n_slots = c->scene.n_regs;
     if (jit_compiled) *jit_compiled = c->jit ? 1 : 0;
+    if (interpreter) *interpreter = c->variant;
+    if (stack_depth) *stack_depth = c->scene.n_stack_prog ? c->scene.stack_depth : 0;
     return 0;
 }
 
@@ -476,7 +500,7 @@ int dcsg_estimate_bounding_box(dcsg_ctx* c, float bb_half, float center[3], floa
     float cdv = cd, hnv = half_neg;
     int* res_ptr = (int*)c->d_small.p;
     void* args[] = {(void*)&blob, &nv, &cdv, &hnv, &bb_eps, (void*)&res_ptr};
-    if ((r = launch(c, c->k->bbox, (unsigned)c->n_cu * 16u, DCSG_BLOCK, c->scene.lds_bytes(), c->stream, args)))
+    if ((r = launch(c, c->k->bbox[c->variant], (unsigned)c->n_cu * 16u, DCSG_BLOCK, c->scene.lds_bytes(), c->stream, args)))
         return r;
     int out[12];
     HIPCHK(c, hipMemcpyAsync(out, c->d_small.p, sizeof(out), hipMemcpyDeviceToHost, c->stream));
@@ -657,7 +681,7 @@ int dcsg_project_vertices_device(dcsg_ctx* c, float* d_xyz, size_t n_vertices, i
     unsigned n = (unsigned)n_vertices;
     unsigned tiles = (n + DCSG_BLOCK - 1) / DCSG_BLOCK;
     void* args[] = {(void*)&blob, &nv, (void*)&d_xyz, &n, &steps};
-    return launch(c, c->k->project, sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), (hipStream_t)stream, args);
+    return launch(c, c->k->project[c->variant], sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), (hipStream_t)stream, args);
 }
 
 int dcsg_project_triangles(dcsg_ctx* c, int steps, void* stream)

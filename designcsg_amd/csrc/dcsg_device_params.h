@@ -16,6 +16,7 @@ struct DcsgLattice {  // ISV3D64 geometry, ISV.hpp:91-109
     float inv_w;      // 1/w, exact when res is a power of two
     int res;          // lattice has (res+1)^3 points
     int w_pow2;       // 1 -> x/w == x*inv_w bit-for-bit
+    unsigned int n1_magic, n1_shift;  // n/(res+1) = (((n - mulhi(n,magic)) >> 1) + mulhi(n,magic)) >> shift
 };
 
 struct DcsgMeshParams {

@@ -52,23 +52,28 @@ __device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_
 }
 #else
 // OpenCL max(gentype x, gentype y): y if x < y, otherwise x
-__device__ __forceinline__ double cl_max_d(double x, double y) { return x < y ? y : x; }
+__device__ __forceinline__ float cl_max_f(float x, float y) { return x < y ? y : x; }
 // The five brushes every scene starts with (scenecompiler.py:424-425, DesignCSG.py:9-22).
-// Unsuffixed literals are double in OpenCL C: subtract in double, narrow at return.
+// Their unsuffixed literals are double in OpenCL C ("length(v)-0.5" subtracts in double and narrows at
+// `return`).  A single +,- on float operands evaluated in double and rounded to float equals the float
+// operation (53 >= 2*24+2 bits: the double rounding is innocuous), and rounding is monotone, so
+// max-then-narrow equals narrow-then-max: the float forms below return the same bits and keep the
+// f64 pipe out of the hot loop.  tests/test_gpu_parity.py::test_builtin_bank_equals_jit_bank pins this
+// against the literal OpenCL text compiled by the OpenCL front-end.
 __device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_id)
 {
     switch (shape_id & 0xff) {  // wave-uniform
     case 0: return (float)K2_MAX_DISTANCE;
     case 1: return 0.0f;
-    case 2: return (float)((double)__builtin_sqrtf(x * x + y * y + z * z) - 0.5);
+    case 2: return __builtin_sqrtf(x * x + y * y + z * z) - 0.5f;
     case 3: {
         float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
         float r = __builtin_sqrtf(ax * ax + az * az);
-        return (float)cl_max_d((double)r - 0.5, (double)ay - 0.5);
+        return cl_max_f(r - 0.5f, ay - 0.5f);
     }
     case 4: {
         float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
-        return (float)cl_max_d((double)ax - 0.5, cl_max_d((double)ay - 0.5, (double)az - 0.5));
+        return cl_max_f(ax - 0.5f, cl_max_f(ay - 0.5f, az - 0.5f));
     }
     default: return 0.0f;  // sdf_bank's trailing "return 0.0;"
     }
@@ -79,8 +84,9 @@ __device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_
 // Scene tables in LDS.
 // Blob (built by csrc/scene.cpp): [0] header {n_steps,n_objects,n_slots,flags}, flags bit 0 =
 // "brush 0 is the constant null brush `return MAX_DISTANCE;`" (always true for the built-in bank;
-// for a JIT-linked scene.cl only when the host verified sd0's body);
-// [1 .. n_steps] steps {opcode,left,right,dest}; then 4 x float4 per object:
+// for a JIT-linked scene.cl only when the host verified sd0's body); [1] header
+// {n_stack_steps, stack_depth, 0, 0}; then the register program, the stack program, the objects:
+// steps {opcode,left,right,dest}; 4 x float4 per object:
 // {pos.xyz, shape_id bits}, {right.xyz,0}, {up.xyz,0}, {forward.xyz,0}.
 // After the blob: the interpreter stack, slot-major (slot*DCSG_BLOCK + tid), so
 // every access is one conflict-free ds_read/ds_write_b32.
@@ -90,8 +96,10 @@ extern __shared__ uint4 dcsg_lds[];
 struct SceneLds {
     const int4* steps;
     const float4* obj;
-    float* stack;  // already offset by threadIdx.x
+    const int4* stack_steps;  // stack program (empty when the program does not nest)
+    float* stack;  // generic interpreter's LDS stack, already offset by threadIdx.x
     int n_steps;
+    int n_stack_steps;
     int flags;
 };
 
@@ -103,15 +111,43 @@ __device__ __forceinline__ SceneLds dcsg_stage_scene(const uint4* __restrict__ b
     int n_steps = __builtin_amdgcn_readfirstlane((int)dcsg_lds[0].x);
     s.n_steps = n_steps;
     s.flags = __builtin_amdgcn_readfirstlane((int)dcsg_lds[0].w);
-    s.steps = reinterpret_cast<const int4*>(dcsg_lds + 1);
-    s.obj = reinterpret_cast<const float4*>(dcsg_lds + 1 + n_steps);
+    int n_stack = __builtin_amdgcn_readfirstlane((int)dcsg_lds[1].x);
+    s.n_stack_steps = n_stack;
+    s.steps = reinterpret_cast<const int4*>(dcsg_lds + 2);
+    s.stack_steps = reinterpret_cast<const int4*>(dcsg_lds + 2 + n_steps);
+    s.obj = reinterpret_cast<const float4*>(dcsg_lds + 2 + n_steps + n_stack);
     s.stack = reinterpret_cast<float*>(dcsg_lds + n_vec4) + threadIdx.x;
     return s;
 }
 
-// primary_sdf, k2.cl:47-144: register machine over the build procedure.
-// Step words are wave-uniform: read once from LDS (broadcast) and moved to SGPRs so the
-// opcode switch and the brush switch are scalar branches, not exec-mask divergence.
+// Internal opcodes: the host (csrc/scene.cpp, fuse_program) rewrites the reference's
+// "IMPORT -> R0; MIN a R0 -> a" / "...; MAX a R0 -> a" / "...; NEGATE R0 -> R0; MAX a R0 -> a"
+// triples, when R0 is dead afterwards, into one accumulate step.  Same comparisons, same operands.
+#define OP_IMPORT_MIN 16     // stack[dest] = T_min(stack[dest], sdf)
+#define OP_IMPORT_MAX 17     // stack[dest] = T_max(stack[dest], sdf)
+#define OP_IMPORT_NEGMAX 18  // stack[dest] = T_max(stack[dest], -sdf)
+
+// ---------------------------------------------------------------------------
+// Generic interpreter: one point, stack in LDS (any slot count up to 64).
+// primary_sdf, k2.cl:47-144.  Step words are wave-uniform: read once from LDS (broadcast) and
+// moved to SGPRs so the opcode switch and the brush switch are scalar branches.
+// Used by the mesher's on-demand samples and as the exact path for waves that hold a -0.0
+// coordinate (see dcsg_stencil).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dcsg_import(const SceneLds& s, int shape, int obj, float x, float y, float z)
+{
+    if (shape == 0 && (s.flags & 1)) return (float)K2_MAX_DISTANCE;  // sd0 ignores v: skip the dead transform
+    float4 q0 = s.obj[4 * obj + 0];
+    float4 q1 = s.obj[4 * obj + 1];
+    float4 q2 = s.obj[4 * obj + 2];
+    float4 q3 = s.obj[4 * obj + 3];
+    float dx = x - q0.x, dy = y - q0.y, dz = z - q0.z;  // k2.cl:105-111
+    float A = dx * q1.x + dy * q1.y + dz * q1.z;        // dot(v-o, right)
+    float B = dx * q2.x + dy * q2.y + dz * q2.z;        // dot(v-o, up)
+    float C = dx * q3.x + dy * q3.y + dz * q3.z;        // dot(v-o, forward)
+    return dcsg_bank(A, B, C, shape);
+}
+
 __device__ __forceinline__ float dcsg_primary_sdf(const SceneLds& s, float x, float y, float z)
 {
     float export_value = (float)K2_MAX_DISTANCE;
@@ -122,24 +158,18 @@ __device__ __forceinline__ float dcsg_primary_sdf(const SceneLds& s, float x, fl
         int right = __builtin_amdgcn_readfirstlane(st.z);
         int dest = __builtin_amdgcn_readfirstlane(st.w);
         switch (op) {
-        case OP_IMPORT: {  // k2.cl:104-113
-            int shape = left & 0xff;
-            float r;
-            if (shape == 0 && (s.flags & 1)) {
-                // sd0 ignores v ("return MAX_DISTANCE;"): skip the dead transform
-                r = (float)K2_MAX_DISTANCE;
-            } else {
-                float4 q0 = s.obj[4 * right + 0];
-                float4 q1 = s.obj[4 * right + 1];
-                float4 q2 = s.obj[4 * right + 2];
-                float4 q3 = s.obj[4 * right + 3];
-                float dx = x - q0.x, dy = y - q0.y, dz = z - q0.z;
-                float A = dx * q1.x + dy * q1.y + dz * q1.z;  // dot(v-o, right)
-                float B = dx * q2.x + dy * q2.y + dz * q2.z;  // dot(v-o, up)
-                float C = dx * q3.x + dy * q3.y + dz * q3.z;  // dot(v-o, forward)
-                r = dcsg_bank(A, B, C, shape);
-            }
-            s.stack[dest * DCSG_BLOCK] = r;
+        case OP_IMPORT: s.stack[dest * DCSG_BLOCK] = dcsg_import(s, left & 0xff, right, x, y, z); break;
+        case OP_IMPORT_MIN: {
+            float a = s.stack[dest * DCSG_BLOCK], b = dcsg_import(s, left & 0xff, right, x, y, z);
+            s.stack[dest * DCSG_BLOCK] = a < b ? a : b;
+        } break;
+        case OP_IMPORT_MAX: {
+            float a = s.stack[dest * DCSG_BLOCK], b = dcsg_import(s, left & 0xff, right, x, y, z);
+            s.stack[dest * DCSG_BLOCK] = a > b ? a : b;
+        } break;
+        case OP_IMPORT_NEGMAX: {
+            float a = s.stack[dest * DCSG_BLOCK], b = -dcsg_import(s, left & 0xff, right, x, y, z);
+            s.stack[dest * DCSG_BLOCK] = a > b ? a : b;
         } break;
         case OP_EXPORT: export_value = s.stack[left * DCSG_BLOCK]; break;
         case OP_MIN: {  // T_min(a,b) (a<b?a:b), k2.cl:29
@@ -171,6 +201,17 @@ __device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
     }
 }
 
+// tail of get_normal, k2.cl:175-177: "1.0/twoE*Dx" is a double product narrowed by the float3 cast
+__device__ __forceinline__ void dcsg_finish_normal(float Dx, float Dy, float Dz, float& nx, float& ny, float& nz)
+{
+    const float twoE = (float)(2.0 * K2_NORMAL_EPSILON);
+    const double k = 1.0 / (double)twoE;
+    nx = (float)(k * (double)Dx);
+    ny = (float)(k * (double)Dy);
+    nz = (float)(k * (double)Dz);
+    dcsg_normalize(nx, ny, nz);
+}
+
 // get_normal, k2.cl:149-179
 __device__ __forceinline__ void dcsg_get_normal(const SceneLds& s, float x, float y, float z, float& nx, float& ny,
                                                 float& nz)
@@ -180,12 +221,170 @@ __device__ __forceinline__ void dcsg_get_normal(const SceneLds& s, float x, floa
     float Dx = dcsg_primary_sdf(s, x + e, y + zero, z + zero) - dcsg_primary_sdf(s, x - e, y - zero, z - zero);
     float Dy = dcsg_primary_sdf(s, x + zero, y + e, z + zero) - dcsg_primary_sdf(s, x - zero, y - e, z - zero);
     float Dz = dcsg_primary_sdf(s, x + zero, y + zero, z + e) - dcsg_primary_sdf(s, x - zero, y - zero, z - e);
-    const float twoE = (float)(2.0 * K2_NORMAL_EPSILON);
-    const double k = 1.0 / (double)twoE;  // "1.0/twoE*Dx": double product, narrowed (k2.cl:177)
-    nx = (float)(k * (double)Dx);
-    ny = (float)(k * (double)Dy);
-    nz = (float)(k * (double)Dz);
-    dcsg_normalize(nx, ny, nz);
+    dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
+}
+
+// Out-of-line copies for the rare exact path of the fast kernels (keeps their code small).
+__device__ __noinline__ float dcsg_primary_sdf_slow(const SceneLds& s, float x, float y, float z)
+{
+    return dcsg_primary_sdf(s, x, y, z);
+}
+
+// ---------------------------------------------------------------------------
+// Fast interpreter: N points per thread in ONE pass over the program, stack in registers.
+//
+// The central-difference normal needs primary_sdf at 7 stencil points.  Interpreting the program
+// once for all of them pays the step decode once, and -- because the unperturbed coordinates of
+// the stencil are passed as the SAME values -- lets the compiler share every common sub-expression
+// of the seven object transforms (value numbering; the arithmetic and its order are unchanged, so
+// results stay bit-identical).
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void dcsg_bank_n(const float (&A)[N], const float (&B)[N], const float (&C)[N], int shape,
+                                            float (&r)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) r[k] = dcsg_bank(A[k], B[k], C[k], shape);
+}
+
+// Stack program (built by the host from the register program when its live ranges nest, which is
+// what the reference scene compiler always emits -- scenecompiler.py:353-387):
+//   PUSH b,o        push sdf(object o, brush b)                      ("IMPORT b,o -> group slot")
+//   ACC_* b,o       top = T_min/T_max(top, +-sdf)                    (fused leaf joins, see above)
+//   POP_*           v = pop(); top = T_min/T_max(top, +-v)           (group joins)
+//   EXPORT_TOP      result = top
+// PUSH/POP carry the stack depth before the step, so the register shifts they need are selected by a
+// wave-uniform compare and every stack access names a fixed register: no indexing, no memory.
+#define SOP_PUSH 32
+#define SOP_ACC_MIN 33
+#define SOP_ACC_MAX 34
+#define SOP_ACC_NEGMAX 35
+#define SOP_POP_MIN 36
+#define SOP_POP_MAX 37
+#define SOP_POP_NEGMAX 38
+#define SOP_EXPORT_TOP 39
+
+template <int D, int N>
+__device__ __forceinline__ void dcsg_interp(const SceneLds& s, const float (&px)[N], const float (&py)[N],
+                                            const float (&pz)[N], float (&out)[N])
+{
+    float stk[D][N];  // stk[0] = top of stack
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int k = 0; k < N; k++) stk[i][k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < N; k++) out[k] = (float)K2_MAX_DISTANCE;
+    for (int c = 0; c < s.n_stack_steps; c++) {
+        int4 st = s.stack_steps[c];
+        int op = __builtin_amdgcn_readfirstlane(st.x);
+        int left = __builtin_amdgcn_readfirstlane(st.y);
+        int right = __builtin_amdgcn_readfirstlane(st.z);
+        int depth = __builtin_amdgcn_readfirstlane(st.w);
+        if (op <= SOP_ACC_NEGMAX) {  // PUSH / ACC_*: evaluate the object at the N points
+            float r[N];
+            int shape = left & 0xff;
+            if (shape == 0 && (s.flags & 1)) {
+#pragma unroll
+                for (int k = 0; k < N; k++) r[k] = (float)K2_MAX_DISTANCE;
+            } else {
+                float4 q0 = s.obj[4 * right + 0];
+                float4 q1 = s.obj[4 * right + 1];
+                float4 q2 = s.obj[4 * right + 2];
+                float4 q3 = s.obj[4 * right + 3];
+                float A[N], B[N], C[N];
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    float dx = px[k] - q0.x, dy = py[k] - q0.y, dz = pz[k] - q0.z;  // k2.cl:105-111
+                    A[k] = dx * q1.x + dy * q1.y + dz * q1.z;
+                    B[k] = dx * q2.x + dy * q2.y + dz * q2.z;
+                    C[k] = dx * q3.x + dy * q3.y + dz * q3.z;
+                }
+                dcsg_bank_n<N>(A, B, C, shape, r);
+            }
+            if (op == SOP_PUSH) {
+#pragma unroll
+                for (int lvl = D - 1; lvl >= 1; lvl--) {
+                    if (depth >= lvl) {
+#pragma unroll
+                        for (int k = 0; k < N; k++) stk[lvl][k] = stk[lvl - 1][k];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < N; k++) stk[0][k] = r[k];
+            } else if (op == SOP_ACC_MIN) {
+#pragma unroll
+                for (int k = 0; k < N; k++) stk[0][k] = stk[0][k] < r[k] ? stk[0][k] : r[k];
+            } else if (op == SOP_ACC_MAX) {
+#pragma unroll
+                for (int k = 0; k < N; k++) stk[0][k] = stk[0][k] > r[k] ? stk[0][k] : r[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    float nb = -r[k];
+                    stk[0][k] = stk[0][k] > nb ? stk[0][k] : nb;
+                }
+            }
+        } else if (op <= SOP_POP_NEGMAX) {  // join the top group into its parent (stk[1])
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                float a = stk[1][k], b = stk[0][k];
+                if (op == SOP_POP_MIN) stk[0][k] = a < b ? a : b;
+                else if (op == SOP_POP_MAX) stk[0][k] = a > b ? a : b;
+                else {
+                    float nb = -b;
+                    stk[0][k] = a > nb ? a : nb;
+                }
+            }
+#pragma unroll
+            for (int lvl = 1; lvl <= D - 2; lvl++) {
+                if (depth > lvl + 1) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) stk[lvl][k] = stk[lvl + 1][k];
+                }
+            }
+        } else if (op == SOP_EXPORT_TOP) {
+#pragma unroll
+            for (int k = 0; k < N; k++) out[k] = stk[0][k];
+        }
+    }
+}
+
+__device__ __forceinline__ bool dcsg_is_neg_zero(float v) { return __float_as_uint(v) == 0x80000000u; }
+
+// SDF and/or normal at one point through the 7-point stencil (or 1 point when only the SDF is wanted).
+// The reference forms the stencil as v +- (eps,0,0): the other coordinates get "+ 0.0f", which changes
+// bits only for -0.0.  A wave holding such a coordinate takes the generic path, every other wave passes
+// the unperturbed coordinates as shared values (see dcsg_interp).
+template <int K>
+__device__ __forceinline__ void dcsg_stencil(const SceneLds& s, float x, float y, float z, bool want_sdf,
+                                             bool want_normal, float& sdf, float& nx, float& ny, float& nz)
+{
+    if (!want_normal) {
+        float p0[1] = {x}, p1[1] = {y}, p2[1] = {z}, o[1];
+        dcsg_interp<K, 1>(s, p0, p1, p2, o);
+        sdf = o[0];
+        return;
+    }
+    bool nzero = dcsg_is_neg_zero(x) || dcsg_is_neg_zero(y) || dcsg_is_neg_zero(z);
+    if (__builtin_amdgcn_ballot_w64(nzero) != 0ull) {
+        if (want_sdf) sdf = dcsg_primary_sdf_slow(s, x, y, z);
+        const float e = (float)K2_NORMAL_EPSILON, zero = 0.0f;
+        float Dx = dcsg_primary_sdf_slow(s, x + e, y + zero, z + zero) - dcsg_primary_sdf_slow(s, x - e, y - zero, z - zero);
+        float Dy = dcsg_primary_sdf_slow(s, x + zero, y + e, z + zero) - dcsg_primary_sdf_slow(s, x - zero, y - e, z - zero);
+        float Dz = dcsg_primary_sdf_slow(s, x + zero, y + zero, z + e) - dcsg_primary_sdf_slow(s, x - zero, y - zero, z - e);
+        dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
+        return;
+    }
+    const float e = (float)K2_NORMAL_EPSILON;
+    float xp = x + e, xm = x - e, yp = y + e, ym = y - e, zp = z + e, zm = z - e;
+    float px[7] = {x, xp, xm, x, x, x, x};
+    float py[7] = {y, y, y, yp, ym, y, y};
+    float pz[7] = {z, z, z, z, z, zp, zm};
+    float o[7];
+    dcsg_interp<K, 7>(s, px, py, pz, o);
+    sdf = o[0];
+    dcsg_finish_normal(o[1] - o[2], o[3] - o[4], o[5] - o[6], nx, ny, nz);
 }
 
 // ISV3D64::getPoint, ISV.hpp:103-109
@@ -205,16 +404,26 @@ __device__ __forceinline__ int dcsg_snap(const DcsgLattice& L, int axis, float p
     return i;
 }
 
+// n / (res+1) for any 32-bit n by multiply-high (round-up method; magic and shift from the host)
+__device__ __forceinline__ unsigned int dcsg_div_n1(const DcsgLattice& L, unsigned int n)
+{
+    unsigned int q = __umulhi(n, L.n1_magic);
+    return (((n - q) >> 1) + q) >> L.n1_shift;
+}
+
 // ---------------------------------------------------------------------------
-// Kernel 1: fused lattice sweep.  One thread per lattice point, x fastest, so a
-// wave stores 256 contiguous bytes of SDF and 768 contiguous bytes of normals.
-// `first` is the flat index of this launch's first point inside the slab buffer,
-// plane z0 is the slab's first plane.  Algorithmic traffic: 16 B written per
-// point, nothing read (positions come from the index, tables from LDS).
+// Kernel 1: fused lattice sweep.  One thread per lattice point, x fastest, so a wave stores
+// 256 contiguous bytes of SDF and 768 contiguous bytes of normals.  `first` is the flat index of
+// this launch's first point inside the slab buffer, plane z0 is the slab's first plane.
+// Algorithmic traffic: 16 B written per point, nothing read (positions come from the index, the
+// op and object tables from LDS).
+// K = stack depth of the register-resident stack interpreter; K = 0 instantiates the generic
+// LDS-stack interpreter (programs that are not stack-disciplined, or deeper than 8).
 // ---------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
-dcsg_sweep(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,
-           unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out)
+template <int K>
+__device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, int n_vec4, const DcsgLattice& L, int z0,
+                                                unsigned int first, unsigned int n_points,
+                                                float* __restrict__ sdf_out, float* __restrict__ nrm_out)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     const unsigned int n1 = (unsigned int)L.res + 1u;
@@ -223,17 +432,22 @@ dcsg_sweep(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, un
         unsigned int local = tile * DCSG_BLOCK + threadIdx.x;
         if (local >= n_points) continue;
         unsigned int idx = first + local;
-        unsigned int ix = idx % n1;
-        unsigned int t = idx / n1;
-        unsigned int iy = t % n1;
-        unsigned int iz = t / n1;
+        unsigned int t = dcsg_div_n1(L, idx);
+        unsigned int ix = idx - t * n1;
+        unsigned int iz = dcsg_div_n1(L, t);
+        unsigned int iy = t - iz * n1;
         float x = dcsg_lattice_coord(L, 0, (int)ix);
         float y = dcsg_lattice_coord(L, 1, (int)iy);
         float z = dcsg_lattice_coord(L, 2, (int)iz + z0);
-        if (sdf_out) sdf_out[idx] = dcsg_primary_sdf(s, x, y, z);
+        float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+        if (K == 0) {
+            if (sdf_out) sd = dcsg_primary_sdf(s, x, y, z);
+            if (nrm_out) dcsg_get_normal(s, x, y, z, nx, ny, nz);
+        } else {
+            dcsg_stencil<(K == 0 ? 4 : K)>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
+        }
+        if (sdf_out) sdf_out[idx] = sd;
         if (nrm_out) {
-            float nx, ny, nz;
-            dcsg_get_normal(s, x, y, z, nx, ny, nz);
             float* o = nrm_out + (size_t)idx * 3;
             o[0] = nx;
             o[1] = ny;
@@ -242,13 +456,25 @@ dcsg_sweep(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, un
     }
 }
 
+#define DCSG_SWEEP_KERNEL(NAME, K)                                                                                  \
+    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                        \
+    NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,                     \
+         unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out)                           \
+    {                                                                                                               \
+        dcsg_sweep_body<K>(blob, n_vec4, L, z0, first, n_points, sdf_out, nrm_out);                                 \
+    }
+DCSG_SWEEP_KERNEL(dcsg_sweep, 0)
+DCSG_SWEEP_KERNEL(dcsg_sweep_s4, 4)
+DCSG_SWEEP_KERNEL(dcsg_sweep_s8, 8)
+
 // ---------------------------------------------------------------------------
 // Kernel 2: k2-equivalent point evaluation (Evaluator::eval_sdf_at_points /
 // eval_normal_at_points).  mode 0 = SDF (1 float/pt), 1 = normal (3 floats/pt).
 // ---------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
-dcsg_eval_points(const uint4* __restrict__ blob, int n_vec4, const float* __restrict__ xyz, unsigned int n, int mode,
-                 float* __restrict__ out)
+template <int K>
+__device__ __forceinline__ void dcsg_eval_points_body(const uint4* __restrict__ blob, int n_vec4,
+                                                      const float* __restrict__ xyz, unsigned int n, int mode,
+                                                      float* __restrict__ out)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     const unsigned int tiles = (n + DCSG_BLOCK - 1) / DCSG_BLOCK;
@@ -256,17 +482,33 @@ dcsg_eval_points(const uint4* __restrict__ blob, int n_vec4, const float* __rest
         unsigned int i = tile * DCSG_BLOCK + threadIdx.x;
         if (i >= n) continue;
         float x = xyz[(size_t)i * 3 + 0], y = xyz[(size_t)i * 3 + 1], z = xyz[(size_t)i * 3 + 2];
-        if (mode == 0) {
-            out[i] = dcsg_primary_sdf(s, x, y, z);
+        float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+        if (K == 0) {
+            if (mode == 0) sd = dcsg_primary_sdf(s, x, y, z);
+            else dcsg_get_normal(s, x, y, z, nx, ny, nz);
         } else {
-            float nx, ny, nz;
-            dcsg_get_normal(s, x, y, z, nx, ny, nz);
+            dcsg_stencil<(K == 0 ? 4 : K)>(s, x, y, z, mode == 0, mode != 0, sd, nx, ny, nz);
+        }
+        if (mode == 0) {
+            out[i] = sd;
+        } else {
             out[(size_t)i * 3 + 0] = nx;
             out[(size_t)i * 3 + 1] = ny;
             out[(size_t)i * 3 + 2] = nz;
         }
     }
 }
+
+#define DCSG_EVAL_KERNEL(NAME, K)                                                                                   \
+    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                        \
+    NAME(const uint4* __restrict__ blob, int n_vec4, const float* __restrict__ xyz, unsigned int n, int mode,       \
+         float* __restrict__ out)                                                                                   \
+    {                                                                                                               \
+        dcsg_eval_points_body<K>(blob, n_vec4, xyz, n, mode, out);                                                  \
+    }
+DCSG_EVAL_KERNEL(dcsg_eval_points, 0)
+DCSG_EVAL_KERNEL(dcsg_eval_points_s4, 4)
+DCSG_EVAL_KERNEL(dcsg_eval_points_s8, 8)
 
 // ---------------------------------------------------------------------------
 // wave / block reductions and scans
@@ -310,8 +552,9 @@ __device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v)
 // result: int[0..2] min index, int[3..5] max index (both seeded by the host with the
 // "no interior point" sentinels), unsigned long long at byte 32: interior count.
 // ---------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
-dcsg_bbox(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, double bb_eps, int* __restrict__ result)
+template <int K>
+__device__ __forceinline__ void dcsg_bbox_body(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg,
+                                               double bb_eps, int* __restrict__ result)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     const unsigned int total = 256u * 256u * 256u;
@@ -325,7 +568,9 @@ dcsg_bbox(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, 
         float x = half_neg + cd * (float)ix;
         float y = half_neg + cd * (float)iy;
         float z = half_neg + cd * (float)iz;
-        float v = dcsg_primary_sdf(s, x, y, z);
+        float v, u0, u1, u2;
+        if (K == 0) v = dcsg_primary_sdf(s, x, y, z);
+        else dcsg_stencil<(K == 0 ? 4 : K)>(s, x, y, z, true, false, v, u0, u1, u2);
         if ((double)v < bb_eps) {  // "p.second < BB_EPSILON", float vs double
             cnt++;
             mn[0] = ix < mn[0] ? ix : mn[0];
@@ -349,6 +594,17 @@ dcsg_bbox(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, 
         atomicAdd(reinterpret_cast<unsigned long long*>(result + 8), (unsigned long long)cnt);
     }
 }
+
+#define DCSG_BBOX_KERNEL(NAME, K)                                                                                   \
+    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                        \
+    NAME(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, double bb_eps,                       \
+         int* __restrict__ result)                                                                                  \
+    {                                                                                                               \
+        dcsg_bbox_body<K>(blob, n_vec4, cd, half_neg, bb_eps, result);                                              \
+    }
+DCSG_BBOX_KERNEL(dcsg_bbox, 0)
+DCSG_BBOX_KERNEL(dcsg_bbox_s4, 4)
+DCSG_BBOX_KERNEL(dcsg_bbox_s8, 8)
 
 // ---------------------------------------------------------------------------
 // Mesher (Mesh::getSurface, mesh.hpp:148-311) on the dense lattice.
@@ -653,8 +909,9 @@ dcsg_mesh_emit(DcsgMeshParams P, const float* __restrict__ nodes, unsigned int n
 // a vertex run in registers: 12 B read + 12 B written per vertex for the whole loop instead of
 // the reference's 100 blocking evaluator round trips.
 // ---------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
-dcsg_project(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ verts, unsigned int n_verts, int steps)
+template <int K>
+__device__ __forceinline__ void dcsg_project_body(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ verts,
+                                                  unsigned int n_verts, int steps)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     const unsigned int tiles = (n_verts + DCSG_BLOCK - 1) / DCSG_BLOCK;
@@ -663,9 +920,13 @@ dcsg_project(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ ver
         if (i >= n_verts) continue;
         float x = verts[(size_t)i * 3 + 0], y = verts[(size_t)i * 3 + 1], z = verts[(size_t)i * 3 + 2];
         for (int k = 0; k < steps; k++) {
-            float sd = dcsg_primary_sdf(s, x, y, z);
-            float nx, ny, nz;
-            dcsg_get_normal(s, x, y, z, nx, ny, nz);
+            float sd, nx, ny, nz;
+            if (K == 0) {
+                sd = dcsg_primary_sdf(s, x, y, z);
+                dcsg_get_normal(s, x, y, z, nx, ny, nz);
+            } else {
+                dcsg_stencil<(K == 0 ? 4 : K)>(s, x, y, z, true, true, sd, nx, ny, nz);
+            }
             float m = -sd;  // v3f_scale(n, -s) then v3f_add, CVector.cpp:128-149
             x = x + m * nx;
             y = y + m * ny;
@@ -676,6 +937,16 @@ dcsg_project(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ ver
         verts[(size_t)i * 3 + 2] = z;
     }
 }
+
+#define DCSG_PROJECT_KERNEL(NAME, K)                                                                                \
+    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                        \
+    NAME(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ verts, unsigned int n_verts, int steps)    \
+    {                                                                                                               \
+        dcsg_project_body<K>(blob, n_vec4, verts, n_verts, steps);                                                  \
+    }
+DCSG_PROJECT_KERNEL(dcsg_project, 0)
+DCSG_PROJECT_KERNEL(dcsg_project_s4, 4)
+DCSG_PROJECT_KERNEL(dcsg_project_s8, 8)
 
 #ifdef DCSG_EXTERN_BANK
 // Points the scene module's program-scope `arbitrary_data` (k2.cl:41,251) at the uploaded table.

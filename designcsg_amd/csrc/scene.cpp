@@ -1,6 +1,7 @@
 // scene.cpp -- parsers for scene.txt / buildprocedure.txt / exportConfig.txt / lookupTable.txt.
 #include "scene.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -115,10 +116,209 @@ bool parse_scene(const char* scene_txt, const char* bp_txt, Scene& s, std::strin
     }
     s.n_slots = max_slot + 1;
     if (s.n_slots < 1) s.n_slots = 1;
+    optimise_program(s);
     return true;
 }
 
-size_t Scene::lds_bytes() const { return blob.size() * 4 + (size_t)n_slots * DCSG_BLOCK * sizeof(float); }
+size_t Scene::lds_bytes() const { return blob.size() * 4 + (size_t)n_regs * DCSG_BLOCK * sizeof(float); }
+
+namespace {
+struct Step {
+    int op, l, r, d;
+};
+enum { IMPORT = 0, EXPORT = 1, MIN = 2, MAX = 3, NEGATE = 4, IDENTITY = 5, IMPORT_MIN = 16, IMPORT_MAX = 17, IMPORT_NEGMAX = 18 };
+
+// slots a step reads / the slot it writes (-1: none)
+void step_access(const Step& t, int reads[2], int& write)
+{
+    reads[0] = reads[1] = write = -1;
+    switch (t.op) {
+    case IMPORT: write = t.d; break;
+    case IMPORT_MIN:
+    case IMPORT_MAX:
+    case IMPORT_NEGMAX: reads[0] = t.d; write = t.d; break;
+    case EXPORT: reads[0] = t.l; break;
+    case MIN:
+    case MAX: reads[0] = t.l; reads[1] = t.r; write = t.d; break;
+    case NEGATE:
+    case IDENTITY: reads[0] = t.l; write = t.d; break;
+    default: break;
+    }
+}
+
+// true when slot R is not read after step j before being overwritten (or the program ends)
+bool dead_after(const std::vector<Step>& p, size_t j, int R)
+{
+    for (size_t k = j + 1; k < p.size(); k++) {
+        int rd[2], wr;
+        step_access(p[k], rd, wr);
+        if (rd[0] == R || rd[1] == R) return false;
+        if (wr == R) return true;
+    }
+    return true;
+}
+}  // namespace
+
+void optimise_program(Scene& s)
+{
+    std::vector<Step> in, out;
+    for (int c = 0; c < s.n_steps; c++) in.push_back({s.steps[4 * c], s.steps[4 * c + 1], s.steps[4 * c + 2], s.steps[4 * c + 3]});
+    // ---- fusion ------------------------------------------------------------------------------
+    for (size_t i = 0; i < in.size(); i++) {
+        const Step& a = in[i];
+        if (a.op == IMPORT && i + 1 < in.size()) {
+            int R = a.d;
+            const Step& b = in[i + 1];
+            // IMPORT -> R ; MIN|MAX x R -> x      (scenecompiler.py:372,377)
+            if ((b.op == MIN || b.op == MAX) && b.r == R && b.l == b.d && b.l != R && dead_after(in, i + 1, R)) {
+                out.push_back({b.op == MIN ? IMPORT_MIN : IMPORT_MAX, a.l, a.r, b.d});
+                i += 1;
+                continue;
+            }
+            // IMPORT -> R ; NEGATE R -> R ; MAX x R -> x   (scenecompiler.py:372-375)
+            if (i + 2 < in.size() && b.op == NEGATE && b.l == R && b.d == R) {
+                const Step& m = in[i + 2];
+                if (m.op == MAX && m.r == R && m.l == m.d && m.l != R && dead_after(in, i + 2, R)) {
+                    out.push_back({IMPORT_NEGMAX, a.l, a.r, m.d});
+                    i += 2;
+                    continue;
+                }
+            }
+        }
+        out.push_back(a);
+    }
+    // ---- stack program ----------------------------------------------------------------------------
+    // The scene compiler's programs are stack-disciplined (scenecompiler.py:353-387: a group imports into
+    // its own slot, accumulates its leaves, recurses into sub-groups and is joined into its parent once).
+    // Replaying the register program on a stack of slot names converts it; any step that does not fit
+    // leaves stack_prog empty and the generic interpreter runs the register program instead.
+    {
+        enum { PUSH = 32, ACC_MIN = 33, ACC_MAX = 34, ACC_NEGMAX = 35, POP_MIN = 36, POP_MAX = 37, POP_NEGMAX = 38, EXPORT_TOP = 39 };
+        std::vector<int> names;  // slot names, back() = top
+        std::vector<Step> sp;
+        bool ok = true;
+        int depth_max = 0;
+        auto on_stack = [&](int v) { return std::find(names.begin(), names.end(), v) != names.end(); };
+        for (size_t i = 0; i < out.size() && ok; i++) {
+            const Step& t = out[i];
+            int n = (int)names.size();
+            switch (t.op) {
+            case IMPORT:
+                if (on_stack(t.d)) { ok = false; break; }
+                sp.push_back({PUSH, t.l, t.r, n});
+                names.push_back(t.d);
+                break;
+            case IMPORT_MIN:
+            case IMPORT_MAX:
+            case IMPORT_NEGMAX:
+                if (n < 1 || names.back() != t.d) { ok = false; break; }
+                sp.push_back({t.op == IMPORT_MIN ? ACC_MIN : (t.op == IMPORT_MAX ? ACC_MAX : ACC_NEGMAX), t.l, t.r, n});
+                break;
+            case MIN:
+            case MAX:  // joinMode parent child -> parent  (scenecompiler.py:384)
+                if (n < 2 || t.d != t.l || names[n - 2] != t.l || names[n - 1] != t.r || !dead_after(out, i, t.r)) { ok = false; break; }
+                sp.push_back({t.op == MIN ? POP_MIN : POP_MAX, 0, 0, n});
+                names.pop_back();
+                break;
+            case NEGATE: {  // NEGATE child -> R0 ; MAX parent R0 -> parent  (scenecompiler.py:381-382)
+                if (i + 1 >= out.size() || n < 2) { ok = false; break; }
+                const Step& m = out[i + 1];
+                int R = t.d;
+                if (names[n - 1] != t.l || on_stack(R) || m.op != MAX || m.r != R || m.l != m.d || names[n - 2] != m.l ||
+                    !dead_after(out, i + 1, R) || !dead_after(out, i + 1, t.l)) { ok = false; break; }
+                sp.push_back({POP_NEGMAX, 0, 0, n});
+                names.pop_back();
+                i += 1;
+            } break;
+            case EXPORT:
+                if (n < 1 || names.back() != t.l) { ok = false; break; }
+                sp.push_back({EXPORT_TOP, 0, 0, n});
+                break;
+            case IDENTITY: ok = false; break;
+            default: break;  // unknown opcodes are ignored by k2.cl's switch
+            }
+            if ((int)names.size() > depth_max) depth_max = (int)names.size();
+        }
+        s.stack_prog.clear();
+        s.n_stack_prog = 0;
+        s.stack_depth = 0;
+        if (ok) {
+            for (const Step& t : sp) {
+                s.stack_prog.push_back(t.op);
+                s.stack_prog.push_back(t.l);
+                s.stack_prog.push_back(t.r);
+                s.stack_prog.push_back(t.d);
+            }
+            s.n_stack_prog = (int)sp.size();
+            s.stack_depth = depth_max;
+        }
+    }
+    // ---- liveness renaming ---------------------------------------------------------------------
+    const int NV = DCSG_MAX_SLOTS;
+    int first[NV], last[NV];
+    bool read_first[NV];
+    for (int v = 0; v < NV; v++) first[v] = last[v] = -2, read_first[v] = false;
+    for (size_t k = 0; k < out.size(); k++) {
+        int rd[2], wr;
+        step_access(out[k], rd, wr);
+        for (int q = 0; q < 2; q++)
+            if (rd[q] >= 0) {
+                if (first[rd[q]] == -2) first[rd[q]] = (int)k, read_first[rd[q]] = true;
+                last[rd[q]] = (int)k;
+            }
+        if (wr >= 0) {
+            if (first[wr] == -2) first[wr] = (int)k;
+            last[wr] = (int)k;
+        }
+    }
+    std::vector<int> order;
+    for (int v = 0; v < NV; v++)
+        if (first[v] != -2) {
+            if (read_first[v]) first[v] = -1;  // read before any write: must own a zeroed register from the start
+            order.push_back(v);
+        }
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return first[a] != first[b] ? first[a] < first[b] : a < b; });
+    int map[NV];
+    for (int v = 0; v < NV; v++) map[v] = 0;
+    std::vector<int> reg_end;  // per physical register: last step of its current tenant
+    for (int v : order) {
+        int pick = -1;
+        for (size_t r = 0; r < reg_end.size(); r++)
+            if (reg_end[r] < first[v] && !read_first[v]) {  // a recycled register is not zero any more
+                pick = (int)r;
+                break;
+            }
+        if (pick < 0) {
+            pick = (int)reg_end.size();
+            reg_end.push_back(last[v]);
+        } else {
+            reg_end[pick] = last[v];
+        }
+        map[v] = pick;
+    }
+    s.n_regs = reg_end.empty() ? 1 : (int)reg_end.size();
+    s.prog.clear();
+    for (const Step& t : out) {
+        Step u = t;
+        switch (t.op) {
+        case IMPORT:
+        case IMPORT_MIN:
+        case IMPORT_MAX:
+        case IMPORT_NEGMAX: u.d = map[t.d]; break;
+        case EXPORT: u.l = map[t.l]; break;
+        case MIN:
+        case MAX: u.l = map[t.l]; u.r = map[t.r]; u.d = map[t.d]; break;
+        case NEGATE:
+        case IDENTITY: u.l = map[t.l]; u.d = map[t.d]; break;
+        default: break;
+        }
+        s.prog.push_back(u.op);
+        s.prog.push_back(u.l);
+        s.prog.push_back(u.r);
+        s.prog.push_back(u.d);
+    }
+    s.n_prog = (int)out.size();
+}
 
 void build_blob(Scene& s, bool null_brush_is_const)
 {
@@ -127,12 +327,18 @@ void build_blob(Scene& s, bool null_brush_is_const)
         memcpy(&u, &f, 4);
         return u;
     };
+    if (s.prog.empty() && s.n_steps) optimise_program(s);
     s.blob.clear();
-    s.blob.push_back((uint32_t)s.n_steps);
+    s.blob.push_back((uint32_t)s.n_prog);
     s.blob.push_back((uint32_t)s.n_objects);
-    s.blob.push_back((uint32_t)s.n_slots);
+    s.blob.push_back((uint32_t)s.n_regs);
     s.blob.push_back(null_brush_is_const ? 1u : 0u);
-    for (int c = 0; c < 4 * s.n_steps; c++) s.blob.push_back((uint32_t)s.steps[c]);
+    s.blob.push_back((uint32_t)s.n_stack_prog);
+    s.blob.push_back((uint32_t)s.stack_depth);
+    s.blob.push_back(0u);
+    s.blob.push_back(0u);
+    for (int c = 0; c < 4 * s.n_prog; c++) s.blob.push_back((uint32_t)s.prog[c]);
+    for (int c = 0; c < 4 * s.n_stack_prog; c++) s.blob.push_back((uint32_t)s.stack_prog[c]);
     for (int i = 0; i < s.n_objects; i++) {
         s.blob.push_back(f2u(s.pos[3 * i]));
         s.blob.push_back(f2u(s.pos[3 * i + 1]));

@@ -15,7 +15,12 @@ struct Scene {
     int n_objects = 0, n_steps = 0, n_slots = 0;
     std::vector<uint8_t> shape;                // [n_objects]
     std::vector<float> pos, right, up, fwd;    // [3*n_objects]
-    std::vector<int32_t> steps;                // [4*n_steps] opcode,left,right,dest
+    std::vector<int32_t> steps;                // [4*n_steps] opcode,left,right,dest  (as in buildprocedure.txt)
+    std::vector<int32_t> prog;                 // internal program: fused + slots renamed (optimise_program)
+    int n_prog = 0;                            // steps in prog
+    int n_regs = 0;                            // stack registers prog needs (<= n_slots)
+    std::vector<int32_t> stack_prog;           // stack program (kernels.hip SOP_*), empty if prog does not nest
+    int n_stack_prog = 0, stack_depth = 0;
     int max_brush_id = 0;                      // over IMPORT steps
     std::vector<uint32_t> blob;                // uint4-granular, see kernels.hip "Scene tables in LDS"
     int blob_vec4() const { return (int)(blob.size() / 4); }
@@ -23,6 +28,11 @@ struct Scene {
 };
 
 bool parse_scene(const char* scene_txt, const char* buildprocedure_txt, Scene& out, std::string& err);
+// Value-preserving rewrite of the build procedure for the device interpreters:
+//  * "IMPORT b,o -> R; MIN a R -> a" (also MAX, and NEGATE R -> R; MAX a R -> a) with R dead afterwards
+//    becomes one accumulate step (opcodes 16/17/18 of kernels.hip): same compare, same operands;
+//  * stack slots are renamed by liveness so that the program needs as few registers as possible.
+void optimise_program(Scene& s);
 void build_blob(Scene& s, bool null_brush_is_const);
 
 // True when scene_cl defines sd0..sd4 exactly as the compiler always does

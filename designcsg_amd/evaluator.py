@@ -84,9 +84,10 @@ class Evaluator:
         return self.build(rd("scene.txt"), rd("buildprocedure.txt"), scl, ad)
 
     def scene_info(self):
-        v = [C.c_int() for _ in range(4)]
+        v = [C.c_int() for _ in range(6)]
         self._ck(self._L.dcsg_scene_info(self._h, *[C.byref(x) for x in v]))
-        return dict(objects=v[0].value, steps=v[1].value, slots=v[2].value, jit=bool(v[3].value))
+        return dict(objects=v[0].value, steps=v[1].value, slots=v[2].value, jit=bool(v[3].value),
+                    interpreter=v[4].value, stack_depth=v[5].value)
 
     # ---- Evaluator::setArbitraryData (Evaluator.cpp:213-225) ------------------------------
     def setArbitraryData(self, data, items=None):

@@ -91,8 +91,12 @@ int dcsg_load_scene(dcsg_ctx* ctx, const char* scene_txt, const char* buildproce
                     const float* arbitrary_data, size_t n_arbitrary);
 /* Evaluator::setArbitraryData (Evaluator.cpp:213-225): copies `items` floats, uploads the whole table. */
 int dcsg_set_arbitrary_data(dcsg_ctx* ctx, const float* data, size_t items);
-/* Scene facts after loading: counts and interpreter stack slots in use. */
-int dcsg_scene_info(const dcsg_ctx* ctx, int* n_objects, int* n_steps, int* n_slots, int* jit_compiled);
+/* Scene facts after loading: object / build-step counts, interpreter registers in use, whether scene.cl
+ * was compiled (1) or the HIP-native brush bank applies (0), which interpreter runs the evaluation
+ * kernels (0 generic LDS stack, 1 register stack depth <= 4, 2 depth <= 8) and the program's stack depth
+ * (0 when it is not stack-disciplined).  Any out pointer may be NULL. */
+int dcsg_scene_info(const dcsg_ctx* ctx, int* n_objects, int* n_steps, int* n_slots, int* jit_compiled,
+                    int* interpreter, int* stack_depth);
 
 /* ---- point evaluation = kernel k2 (k2.cl:234-280) ---------------------------------- */
 /* Evaluator::eval_sdf_at_points (Evaluator.cpp:117-165): xyz = n x 3 floats, out = n floats. */

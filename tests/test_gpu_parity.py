@@ -40,9 +40,20 @@ def sorted_tris(t):
     return b[np.lexsort(b.T[::-1])]
 
 
+EXPECTED_STACK_DEPTH = {"sphere": 1, "design1": 1, "design2": 1, "flat256": 1, "mixed_groups": 2, "grouped256": 2}
+
+
+@pytest.mark.parametrize("interpreter", ["auto", "generic"])
 @pytest.mark.parametrize("name", ALL_SCENES)
-def test_point_eval_bit_exact(ev, oracle, name):
+def test_point_eval_bit_exact(ev, oracle, name, interpreter, monkeypatch):
+    """Both device interpreters (register-stack program / generic LDS-stack program) against the oracle,
+    which runs the build procedure exactly as buildprocedure.txt states it."""
+    if interpreter == "generic":
+        monkeypatch.setenv("DCSG_FORCE_VARIANT", "0")
     load(ev, name)
+    info = ev.scene_info()
+    assert info["stack_depth"] == EXPECTED_STACK_DEPTH[name]
+    assert info["interpreter"] == (0 if interpreter == "generic" else 1)
     osc = oracle.Scene.from_dir(scene_dir(name))
     rng = np.random.default_rng(7)
     n = 200_000 if name in ("sphere", "design1", "design2") else 40_000
