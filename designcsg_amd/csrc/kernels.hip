@@ -239,12 +239,46 @@ __device__ __noinline__ float dcsg_primary_sdf_slow(const SceneLds& s, float x, 
 // of the seven object transforms (value numbering; the arithmetic and its order are unchanged, so
 // results stay bit-identical).
 // ---------------------------------------------------------------------------
+// Brush evaluation at N points: ONE wave-uniform dispatch, then N independent straight-line bodies in a
+// single basic block (lets the scheduler interleave them and use packed f32 math).
 template <int N>
 __device__ __forceinline__ void dcsg_bank_n(const float (&A)[N], const float (&B)[N], const float (&C)[N], int shape,
                                             float (&r)[N])
 {
+#ifdef DCSG_EXTERN_BANK
 #pragma unroll
     for (int k = 0; k < N; k++) r[k] = dcsg_bank(A[k], B[k], C[k], shape);
+#else
+    switch (shape & 0xff) {
+    case 0:
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = (float)K2_MAX_DISTANCE;
+        break;
+    case 2:
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = __builtin_sqrtf(A[k] * A[k] + B[k] * B[k] + C[k] * C[k]) - 0.5f;
+        break;
+    case 3:
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            float ax = __builtin_fabsf(A[k]), ay = __builtin_fabsf(B[k]), az = __builtin_fabsf(C[k]);
+            float rad = __builtin_sqrtf(ax * ax + az * az);
+            r[k] = cl_max_f(rad - 0.5f, ay - 0.5f);
+        }
+        break;
+    case 4:
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            float ax = __builtin_fabsf(A[k]), ay = __builtin_fabsf(B[k]), az = __builtin_fabsf(C[k]);
+            r[k] = cl_max_f(ax - 0.5f, cl_max_f(ay - 0.5f, az - 0.5f));
+        }
+        break;
+    default:  // brush 1 ("return 0.0;") and sdf_bank's trailing "return 0.0;"
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = 0.0f;
+        break;
+    }
+#endif
 }
 
 // Stack program (built by the host from the register program when its live ranges nest, which is
