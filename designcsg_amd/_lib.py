@@ -67,11 +67,15 @@ PROTOTYPES = {
     "dcsg_project_vertices_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "dcsg_triangles_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "dcsg_download_triangles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "dcsg_copy_triangles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "dcsg_write_stl": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
     "dcsg_write_ply": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
     "dcsg_parse_export_config": (C.c_int, [C.c_char_p, C.POINTER(ExportConfig)]),
     "dcsg_export": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint, C.POINTER(ExportStats)]),
     "dcsg_last_sweep_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "dcsg_compile_program": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    "dcsg_expand_lookup_table": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]),
     "dcsg_jit_prebuild": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
 }
 

@@ -710,6 +710,18 @@ int dcsg_download_triangles(dcsg_ctx* c, float* out, uint64_t max_triangles)
     return 0;
 }
 
+int dcsg_copy_triangles_device(dcsg_ctx* c, float* d_out, uint64_t max_triangles, void* stream)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    if (max_triangles < c->n_tris) return fail(c, DCSG_ERR_INVALID, "output buffer too small");
+    if (!c->n_tris) return 0;
+    if (!d_out) return fail(c, DCSG_ERR_INVALID, "NULL output buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(d_out, c->d_tris.p, (size_t)c->n_tris * 9 * sizeof(float), hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
+    return 0;
+}
+
 // writeTrianglesToSTL, utils.hpp:41-103: 80 zero bytes, u32 count, per triangle a zero normal, then
 // A, B, C each written as (x, z, y), then u16 0.  Little-endian host assumed (x86-64).
 int dcsg_write_stl(const char* path, const float* tris, uint64_t n)
@@ -764,6 +776,34 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
     size_t w = fwrite(buf.data(), 1, bytes, f);
     int ok = fclose(f) == 0 && w == bytes;
     return ok ? 0 : DCSG_ERR_IO;
+}
+
+int dcsg_compile_program(const char* scene_txt, const char* bp_txt, int32_t* reg_prog, int* n_reg_steps, int* n_regs,
+                         int32_t* stack_prog, int* n_stack_steps, int* stack_depth, int cap)
+{
+    Scene s;
+    std::string err;
+    if (!parse_scene(scene_txt, bp_txt, s, err)) return fail(nullptr, DCSG_ERR_INVALID, err);
+    if (s.n_prog > cap || s.n_stack_prog > cap) return fail(nullptr, DCSG_ERR_INVALID, "output arrays too small");
+    if (reg_prog) memcpy(reg_prog, s.prog.data(), s.prog.size() * sizeof(int32_t));
+    if (stack_prog) memcpy(stack_prog, s.stack_prog.data(), s.stack_prog.size() * sizeof(int32_t));
+    if (n_reg_steps) *n_reg_steps = s.n_prog;
+    if (n_regs) *n_regs = s.n_regs;
+    if (n_stack_steps) *n_stack_steps = s.n_stack_prog;
+    if (stack_depth) *stack_depth = s.stack_depth;
+    return 0;
+}
+
+int dcsg_expand_lookup_table(const char* txt, uint8_t table[4096], int* total)
+{
+    std::vector<uint8_t> t;
+    int n = 0;
+    std::string err;
+    if (!txt || !table) return DCSG_ERR_INVALID;
+    if (!parse_lookup_table(txt, t, n, err)) return fail(nullptr, DCSG_ERR_INVALID, err);
+    memcpy(table, t.data(), 4096);
+    if (total) *total = n;
+    return 0;
 }
 
 // MyFrame::OnExportInner, DesignCSG.cpp:638-790

@@ -170,6 +170,10 @@ class Evaluator:
         self._ck(self._L.dcsg_download_triangles(self._h, _fptr(out), n))
         return out
 
+    def copy_triangles_device(self, d_out, max_triangles, stream=0):
+        self._ck(self._L.dcsg_copy_triangles_device(self._h, C.c_void_p(d_out), max_triangles,
+                                                    C.c_void_p(stream or None)))
+
     def export(self, export_config_txt, stl_path=None, ply_path=None, dense_normals=False):
         """MyFrame::OnExportInner end to end on this GPU."""
         st = ExportStats()

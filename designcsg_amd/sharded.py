@@ -1,0 +1,130 @@
+"""Z-slab sharded export: one process per GPU, torch.distributed (RCCL over xGMI on GPUs).
+
+The lattice values are a pure function of position and octree subtrees are independent, so the export
+shards by Z: rank r of N owns lattice planes [r*res/N, (r+1)*res/N) -- the last rank
+also owns plane res -- sweeps them, and needs exactly ONE plane it does not own: plane (r+1)*res/N, the
+upper face of its top cells, which its upper neighbour owns as its first plane.  That halo plane is the
+only data-path exchange (point-to-point send/recv between Z neighbours); coarse octree nodes that
+straddle slabs are processed redundantly by every rank from on-demand samples.  Triangles are then
+gathered to rank 0 (counts by all_gather, payload by gather), which writes the files.
+
+The compute backend is an object with the four methods of `HipBackend`; the product always uses
+`HipBackend` (libdcsg_hip through the C ABI).  tests/test_sharded_gloo.py injects a CPU checker backend to
+run this driver's partition / halo / gather logic under gloo with world_size 2 -- there is no CPU
+backend in this package and none is selected automatically.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def slab_ranges(res, world):
+    """[(lo, hi)] per rank: own planes lo..hi-1, halo plane hi; the last rank also owns plane res."""
+    if world < 1 or res % world != 0:
+        raise ValueError("grid resolution %d does not split into %d equal Z slabs" % (res, world))
+    return [(r * res // world, (r + 1) * res // world) for r in range(world)]
+
+
+class HipBackend:
+    """The MI355X path: lattice slabs live in torch tensors on this rank's GPU, kernels run through
+    libdcsg_hip on torch's current stream."""
+
+    def __init__(self, evaluator, device):
+        self.ev = evaluator
+        self.device = torch.device(device)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def estimate_bounding_box(self, bb_half):
+        return self.ev.estimate_bounding_box(bb_half)
+
+    def sweep(self, center, diameter, res, z0, z1, sdf, normals):
+        """Fill planes z0..z1-1 into the given slab tensors (normals may be None)."""
+        self.ev.sweep_lattice_device(center, diameter, res, z0, z1, sdf.data_ptr(),
+                                     0 if normals is None else normals.data_ptr(), self._stream())
+
+    def alloc(self, n_floats):
+        return torch.empty(n_floats, dtype=torch.float32, device=self.device)
+
+    def mesh(self, center, diameter, cfg, sdf, normals, z_lo, z_hi, own_lo, own_hi):
+        n, st = self.ev.mesh_lattice_device(center, diameter, cfg, sdf.data_ptr(),
+                                            0 if normals is None else normals.data_ptr(), z_lo, z_hi, own_lo, own_hi,
+                                            self._stream())
+        return n, st
+
+    def project_and_fetch(self, steps):
+        """Projection of the meshed triangles, returned as a (T,3,3) float32 tensor on this device."""
+        self.ev.project_triangles(steps, self._stream())
+        _, n = self.ev.triangles_device()
+        out = torch.empty((n, 3, 3), dtype=torch.float32, device=self.device)
+        self.ev.copy_triangles_device(out.data_ptr(), n, self._stream())
+        return out
+
+
+def exchange_halo(sdf, normals, plane_floats, n_own, rank, world, group=None):
+    """Plane 0 of every rank > 0 goes to the halo plane (index n_own) of rank-1.  Point-to-point between Z
+    neighbours: on xGMI each pair has a direct link, so nothing is routed through a ring."""
+    reqs = []
+    if rank > 0:
+        reqs.append(dist.isend(sdf[:plane_floats], rank - 1, group=group))
+        if normals is not None:
+            reqs.append(dist.isend(normals[:3 * plane_floats], rank - 1, group=group))
+    if rank < world - 1:
+        reqs.append(dist.irecv(sdf[n_own * plane_floats:(n_own + 1) * plane_floats], rank + 1, group=group))
+        if normals is not None:
+            reqs.append(dist.irecv(normals[3 * n_own * plane_floats:3 * (n_own + 1) * plane_floats], rank + 1,
+                                   group=group))
+    for r in reqs:
+        r.wait()
+
+
+def gather_triangles(tris, rank, world, group=None):
+    """Variable-length gather to rank 0: counts by all_gather, payload padded to the largest count.
+    Returns (concatenated (T,3,3) tensor on rank 0 else None, list of per-rank counts)."""
+    count = torch.tensor([tris.shape[0]], dtype=torch.int64, device=tris.device)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    padded = torch.zeros((cap, 3, 3), dtype=torch.float32, device=tris.device)
+    padded[:tris.shape[0]] = tris
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, bufs, dst=0, group=group)
+    if rank != 0:
+        return None, counts
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)]), counts
+
+
+def sharded_export(backend, cfg, rank, world, dense_normals=False, group=None, check_halo=False):
+    """Runs the export stages on this rank's slab.  cfg: ExportConfig (parse_export_config).
+    Returns dict(triangles=(T,3,3) CPU numpy array on rank 0 / None elsewhere, counts, box, stats)."""
+    center, diameter, interior = backend.estimate_bounding_box(cfg.bounding_box_half_diameter)
+    res = 1 << cfg.grid_level
+    n1 = res + 1
+    plane = n1 * n1
+    lo, hi = slab_ranges(res, world)[rank]
+    last = rank == world - 1
+    n_own = hi - lo + (1 if last else 0)      # planes this rank computes
+    n_res = hi - lo + 1                       # planes resident for meshing: lo..hi
+    sdf = backend.alloc(n_res * plane)
+    nrm = backend.alloc(3 * n_res * plane) if dense_normals else None
+    # own planes (the halo plane hi is the neighbour's, except on the last rank)
+    backend.sweep(center, diameter, res, lo, lo + n_own, sdf, nrm)
+    if world > 1:
+        exchange_halo(sdf, nrm, plane, hi - lo, rank, world, group)
+        if check_halo and not last:
+            # self-check: the received plane must equal what this rank computes for it
+            chk = backend.alloc(plane)
+            backend.sweep(center, diameter, res, hi, hi + 1, chk, None)
+            if not torch.equal(chk.view(torch.int32), sdf[(hi - lo) * plane:(hi - lo + 1) * plane].view(torch.int32)):
+                raise RuntimeError("halo plane %d from rank %d differs from the local evaluation" % (hi, rank + 1))
+    n_tris, stats = backend.mesh(center, diameter, cfg, sdf, nrm, lo, hi, lo, hi)
+    tris = backend.project_and_fetch(cfg.gradient_descent_steps)
+    assert tris.shape[0] == n_tris
+    if world > 1:
+        all_tris, counts = gather_triangles(tris, rank, world, group)
+    else:
+        all_tris, counts = tris, [int(tris.shape[0])]
+    return dict(triangles=None if all_tris is None else all_tris.cpu().numpy(), counts=counts,
+                box=(center, diameter, interior), stats=stats, slab=(lo, hi))

@@ -136,6 +136,9 @@ int dcsg_project_vertices_device(dcsg_ctx* ctx, float* d_xyz, size_t n_vertices,
 /* Device pointer / host copy of the context's triangle buffer. */
 int dcsg_triangles_device(dcsg_ctx* ctx, const float** d_triangles, uint64_t* n_triangles);
 int dcsg_download_triangles(dcsg_ctx* ctx, float* out, uint64_t max_triangles);
+/* Asynchronous device-to-device copy of the triangle buffer into caller-owned device memory (e.g. a torch
+ * tensor that is then gathered over RCCL). */
+int dcsg_copy_triangles_device(dcsg_ctx* ctx, float* d_out, uint64_t max_triangles, void* stream);
 
 /* cms::writeTrianglesToSTL (utils.hpp:41-103) / writeTrianglesToPLY (utils.hpp:106-154). */
 int dcsg_write_stl(const char* path, const float* triangles, uint64_t n_triangles);
@@ -151,6 +154,18 @@ int dcsg_export(dcsg_ctx* ctx, const char* export_config_txt, const char* stl_pa
 
 /* Device time in ms of the most recent lattice sweep (HIP events on its stream; synchronises). */
 int dcsg_last_sweep_ms(dcsg_ctx* ctx, double* ms);
+
+/* ---- host-only diagnostics (no device needed; used by the CPU test-suite) ---------------------- */
+/* What dcsg_load_scene makes of a build procedure: the register program after fusion and slot renaming
+ * (4 ints per step: opcode,left,right,dest; opcodes 0-5 of k2.cl:12-17 plus 16 IMPORT_MIN, 17 IMPORT_MAX,
+ * 18 IMPORT_NEGMAX) and, when the program is stack-disciplined, the stack program (32 PUSH, 33-35 ACC_MIN/
+ * MAX/NEGMAX, 36-38 POP_MIN/MAX/NEGMAX, 39 EXPORT_TOP; 4th int = stack depth before the step).
+ * cap = capacity of each output array in steps.  Returns DCSG_ERR_INVALID for a malformed scene. */
+int dcsg_compile_program(const char* scene_txt, const char* buildprocedure_txt, int32_t* reg_prog, int* n_reg_steps,
+                         int* n_regs, int32_t* stack_prog, int* n_stack_steps, int* stack_depth, int cap);
+/* lookupTable.txt expanded as the kernels see it: table[case*16] = triangle count, then 3 edge ids per
+ * triangle (cms::getIndexTrianglesFromTable + getIndexTriangleStrip). */
+int dcsg_expand_lookup_table(const char* lookup_table_txt, uint8_t table[4096], int* total_triangles);
 
 /* The compile half of Evaluator::build without a device: compiles scene_cl into the on-disk code
  * object cache (used at install time so that known scenes load without compiling).  The compiler

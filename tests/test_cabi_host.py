@@ -1,0 +1,266 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports exactly what include/dcsg.h
+declares, fails loudly without a GPU, and its host logic (parsers, writers, lookup-table expansion,
+build-procedure optimiser, brush JIT) agrees with the oracle.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, TABLE, read_scene, scene_dir
+
+HEADER = os.path.join(ROOT, "include", "dcsg.h")
+ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256"]
+
+
+def declared_functions():
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(dcsg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from designcsg_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(built_lib, n), "libdcsg_hip.so does not export " + n
+    assert sorted(_lib.PROTOTYPES) == names, "ctypes prototypes and include/dcsg.h disagree"
+
+
+def test_no_symbol_of_the_oracle_is_linked(built_lib):
+    import subprocess
+    from designcsg_amd import _lib
+    out = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle_" not in out
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libdcsg_oracle" not in needed and "libamdhip64" in needed
+
+
+def test_product_sources_never_touch_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "designcsg_amd")):
+        if "_build" in base:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".cl")):
+                t = open(os.path.join(base, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|#include\s+[\"<].*oracle", t, re.M):
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_create_fails_loudly_without_a_gpu(built_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from designcsg_amd import _lib
+    from designcsg_amd.evaluator import Evaluator
+    with pytest.raises(_lib.DcsgError) as ei:
+        Evaluator(0)
+    assert ei.value.code == _lib.ERR_NO_DEVICE and "no CPU fallback" in ei.value.message
+
+
+def test_import_fails_loudly_when_the_library_is_missing(monkeypatch):
+    from designcsg_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdcsg_hip.so")
+    with pytest.raises(ImportError):
+        _lib.lib()
+
+
+def test_export_config_parser(built_lib, oracle):
+    from designcsg_amd.evaluator import parse_export_config
+    for name in ALL_SCENES:
+        txt = read_scene(name)["exportConfig.txt"]
+        a, b = parse_export_config(txt), oracle.parse_export_config(txt)
+        for f, _ in a._fields_:
+            assert getattr(a, f) == getattr(b, f), (name, f)
+    a = parse_export_config("10.0\n6\n8\n9\n0.7853981633974483\n50\n16\n512\n4096\n")
+    assert (a.bounding_box_half_diameter, a.min_level, a.max_level, a.grid_level) == (10.0, 6, 8, 9)
+    assert a.complex_surface_threshold == np.float32(0.7853981633974483)
+    with pytest.raises(ValueError):
+        parse_export_config("10.0\n6\n8\n")
+
+
+def test_writers_byte_identical_to_oracle(built_lib, oracle, tmp_path):
+    from designcsg_amd.evaluator import write_ply, write_stl
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 1000):
+        tris = rng.normal(size=(n, 3, 3)).astype(np.float32)
+        write_stl(tmp_path / "a.stl", tris)
+        write_ply(tmp_path / "a.ply", tris)
+        oracle.write_stl(str(tmp_path / "b.stl"), tris)
+        oracle.write_ply(str(tmp_path / "b.ply"), tris)
+        stl, ply = (tmp_path / "a.stl").read_bytes(), (tmp_path / "a.ply").read_bytes()
+        assert stl == (tmp_path / "b.stl").read_bytes()
+        assert ply == (tmp_path / "b.ply").read_bytes()
+        # utils.hpp:41-103: 80 zero bytes, count, 50-byte records, (x, z, y) order, zero normals
+        assert len(stl) == 84 + 50 * n and stl[:80] == bytes(80) and int.from_bytes(stl[80:84], "little") == n
+        if n:
+            rec = np.frombuffer(stl[84:134], dtype=np.uint8)
+            f = rec[:48].view(np.float32)
+            assert (f[:3] == 0).all() and f[3] == tris[0, 0, 0] and f[4] == tris[0, 0, 2] and f[5] == tris[0, 0, 1]
+        # utils.hpp:106-154 / happly: exact header, doubles, uchar+3*uint faces
+        hdr = ("ply\nformat binary_little_endian 1.0\ncomment Written with hapPLY (https://github.com/nmwsharp/happly)\n"
+               "element vertex %d\nproperty double x\nproperty double y\nproperty double z\n"
+               "element face %d\nproperty list uchar uint vertex_indices\nend_header\n" % (3 * n, n)).encode()
+        assert ply.startswith(hdr) and len(ply) == len(hdr) + 85 * n
+
+
+def test_lookup_table_expansion_matches_oracle(built_lib, lookup_table):
+    table = np.zeros(4096, dtype=np.uint8)
+    total = C.c_int()
+    assert built_lib.dcsg_expand_lookup_table(open(TABLE, "rb").read(), table.ctypes.data_as(C.c_void_p),
+                                              C.byref(total)) == 0
+    assert total.value == lookup_table.total == 820
+    t = table.reshape(256, 16)
+    for case in range(256):
+        n = int(lookup_table.count[case])
+        assert t[case, 0] == n
+        assert t[case, 1:1 + 3 * n].tolist() == lookup_table.tris[case, :n].reshape(-1).tolist()
+    bad = np.zeros(4096, dtype=np.uint8)
+    assert built_lib.dcsg_expand_lookup_table(b"0,3,8\n", bad.ctypes.data_as(C.c_void_p), None) != 0
+
+
+# ---- build-procedure optimiser -------------------------------------------------------------------
+def compile_program(lib, scene_txt, bp_txt, cap=4096):
+    reg = np.zeros((cap, 4), dtype=np.int32)
+    stk = np.zeros((cap, 4), dtype=np.int32)
+    n_reg, n_regs, n_stk, depth = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib.dcsg_compile_program(scene_txt.encode(), bp_txt.encode(), reg.ctypes.data_as(C.c_void_p), C.byref(n_reg),
+                                  C.byref(n_regs), stk.ctypes.data_as(C.c_void_p), C.byref(n_stk), C.byref(depth), cap)
+    return rc, reg[:n_reg.value], n_regs.value, stk[:n_stk.value], depth.value
+
+
+class object_values(dict):
+    """(brush b, object i) -> sdf_bank(local(v, object i), b) from the oracle: the value an IMPORT yields."""
+
+    def __init__(self, oracle, scene, pts):
+        super().__init__()
+        self.oracle, self.scene, self.pts = oracle, scene, pts
+        self.cl = os.path.join(scene["dir"], "scene.cl")
+
+    def __missing__(self, key):
+        brush, obj = key
+        mini = self.oracle.Scene(self.scene["scene.txt"], "0 %d %d 0\n1 0 -1 -1" % (brush, obj), self.cl)
+        self[key] = mini.eval_sdf(self.pts)
+        return self[key]
+
+
+def tmin(a, b):
+    return np.where(a < b, a, b)
+
+
+def tmax(a, b):
+    return np.where(a > b, a, b)
+
+
+def run_register_program(prog, n_regs, imp, n):
+    st = np.zeros((max(n_regs, 1), n), dtype=np.float32)
+    out = np.full(n, 64.0, dtype=np.float32)
+    for op, l, r, d in prog.tolist():
+        if op == 0: st[d] = imp[(l & 255, r)]
+        elif op == 16: st[d] = tmin(st[d], imp[(l & 255, r)])
+        elif op == 17: st[d] = tmax(st[d], imp[(l & 255, r)])
+        elif op == 18: st[d] = tmax(st[d], -imp[(l & 255, r)])
+        elif op == 1: out = st[l].copy()
+        elif op == 2: st[d] = tmin(st[l], st[r])
+        elif op == 3: st[d] = tmax(st[l], st[r])
+        elif op == 4: st[d] = -st[l]
+        elif op == 5: st[d] = st[l].copy()
+    return out
+
+
+def run_stack_program(prog, imp, n):
+    st = []
+    out = np.full(n, 64.0, dtype=np.float32)
+    for op, l, r, depth in prog.tolist():
+        assert depth == len(st), "recorded depth must equal the stack depth before the step"
+        if op == 32: st.append(imp[(l & 255, r)].copy())
+        elif op == 33: st[-1] = tmin(st[-1], imp[(l & 255, r)])
+        elif op == 34: st[-1] = tmax(st[-1], imp[(l & 255, r)])
+        elif op == 35: st[-1] = tmax(st[-1], -imp[(l & 255, r)])
+        elif op in (36, 37, 38):
+            v = st.pop()
+            st[-1] = tmin(st[-1], v) if op == 36 else (tmax(st[-1], v) if op == 37 else tmax(st[-1], -v))
+        elif op == 39: out = st[-1].copy()
+    return out
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_program_optimiser_preserves_values(built_lib, oracle, name):
+    """The fused/renamed register program and the stack program, interpreted in numpy float32 over the
+    oracle's per-object values, give the oracle's result for the ORIGINAL buildprocedure.txt, bit for bit."""
+    sc = read_scene(name)
+    sc["dir"] = scene_dir(name)
+    rc, reg, n_regs, stk, depth = compile_program(built_lib, sc["scene.txt"], sc["buildprocedure.txt"])
+    assert rc == 0
+    n_orig = len(sc["buildprocedure.txt"].split("\n"))
+    assert len(reg) < n_orig and n_regs <= 3          # fusion shortens, renaming needs root + group + R0 at most
+    assert len(stk) > 0 and depth in (1, 2)           # compiler output is stack-disciplined
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-5, 5, (3000 if name in ("flat256", "grouped256") else 20000, 3)).astype(np.float32)
+    want = oracle.Scene.from_dir(scene_dir(name)).eval_sdf(pts)
+    imp = object_values(oracle, sc, pts)
+    assert np.array_equal(run_register_program(reg, n_regs, imp, len(pts)).view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(run_stack_program(stk, imp, len(pts)).view(np.uint32), want.view(np.uint32))
+
+
+def test_program_optimiser_on_hand_written_programs(built_lib, oracle):
+    scene_txt = read_scene("mixed_groups")["scene.txt"]
+    cases = {
+        # R0 (slot 1) is read again later: no fusion of the first pair, and not stack-disciplined
+        "live_r0": "0 2 1 1\n2 0 1 0\n0 3 2 0\n3 0 1 0\n1 0 -1 -1",
+        # MIN with the operands the other way round must not be fused (T_min is not symmetric in bits)
+        "swapped": "0 0 0 0\n0 2 1 1\n2 1 0 0\n1 0 -1 -1",
+        # IDENTITY / NEGATE on their own
+        "ident": "0 2 1 0\n5 0 -1 2\n4 2 -1 3\n3 0 3 0\n1 0 -1 -1",
+        # a slot that is read before anything writes it (zero-initialised stack)
+        "uninit": "0 2 1 1\n2 5 1 0\n1 0 -1 -1",
+        # export of a slot other than the last one written
+        "export_mid": "0 2 1 0\n0 3 2 1\n1 0 -1 -1",
+        # unknown opcode is ignored (k2.cl's switch has no default)
+        "unknown": "0 2 1 0\n9 0 0 0\n1 0 -1 -1",
+        "empty": "",
+    }
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-5, 5, (5000, 3)).astype(np.float32)
+    sc = {"scene.txt": scene_txt, "dir": scene_dir("mixed_groups")}
+    imp = object_values(oracle, sc, pts)
+    for key, bp in cases.items():
+        rc, reg, n_regs, stk, depth = compile_program(built_lib, scene_txt, bp)
+        assert rc == 0, key
+        want = oracle.Scene(scene_txt, bp, os.path.join(sc["dir"], "scene.cl")).eval_sdf(pts)
+        got = run_register_program(reg, n_regs, imp, len(pts))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), key
+        if len(stk):
+            assert np.array_equal(run_stack_program(stk, imp, len(pts)).view(np.uint32), want.view(np.uint32)), key
+    assert len(compile_program(built_lib, scene_txt, cases["live_r0"])[3]) == 0
+    assert [s[0] for s in compile_program(built_lib, scene_txt, cases["swapped"])[1].tolist()] == [0, 0, 2, 1]
+
+
+def test_scene_validation(built_lib):
+    scene_txt = read_scene("sphere")["scene.txt"]
+    for bad in ("0 2 7 1\n1 0 -1 -1",       # object 7 of 2
+                "0 2 1 64\n1 0 -1 -1",      # slot 64 (STACK_MEMORY_PER_PIXEL = 64)
+                "0 2 1 -1\n1 0 -1 -1",      # negative destination
+                "2 0 99 0\n1 0 -1 -1",
+                "0 2 1\n"):                 # short line
+        assert compile_program(built_lib, scene_txt, bad)[0] != 0, bad
+    assert compile_program(built_lib, "0 1 0 0 0 0.2 0 0\n", "1 0 -1 -1")[0] != 0  # short scene.txt row
+
+
+def test_brush_jit_without_a_gpu(built_lib, tmp_path, monkeypatch):
+    """Evaluator::build's compile half: good source -> code object in the cache, bad source -> the log."""
+    monkeypatch.setenv("DCSG_JIT_CACHE", str(tmp_path))
+    src = read_scene("design2")["scene.cl"].encode()
+    log = C.create_string_buffer(1 << 16)
+    cached = C.c_int(-1)
+    assert built_lib.dcsg_jit_prebuild(src, log, len(log), C.byref(cached)) == 0 and cached.value == 0
+    objs = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert len(objs) == 1 and open(tmp_path / objs[0], "rb").read(4) == b"\x7fELF"
+    assert built_lib.dcsg_jit_prebuild(src, log, len(log), C.byref(cached)) == 0 and cached.value == 1
+    bad = src.replace(b"hilbert_sdf(v)", b"no_such_function(v)")
+    assert built_lib.dcsg_jit_prebuild(bad, log, len(log), C.byref(cached)) == -4
+    assert b"no_such_function" in log.value

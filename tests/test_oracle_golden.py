@@ -1,0 +1,125 @@
+"""Pins the CPU oracle to the golden vectors of SURVEY.md section 8(c) (obtained there by running the
+reference's own k2.cl / mesh.hpp on the CPU) -- every SDF / normal / lattice / stage-A / triangle-count /
+vertex-sum figure the survey records for configurations that run in seconds.  The 512^3 and 1024^3
+figures are pinned by tests/golden/big_configs.json (generated once by tests/golden/make_big_goldens.py
+with this oracle and checked there against the same section)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, export_config_text, scene_dir
+
+
+@pytest.fixture(scope="module")
+def d2(oracle):
+    return oracle.Scene.from_dir(scene_dir("design2"))
+
+
+def test_sdf_probe_points(d2):
+    gold = [((0, 0, 0), 0.400000006), ((1, 0, 0), 0.312132955), ((0, -4.3, 0), -0.0485253334),
+            ((2.5, 2.5, 2.5), 0.960657477), ((0.3, 0.1, -0.7), 0.322426319)]
+    for p, want in gold:
+        assert np.float32(d2.sdf(*map(float, p))) == np.float32(want)
+
+
+def test_normal_probe_points(d2):
+    gold = [((1, 0, 0), (-0.146448418, -0.499992907, 0.853557229)), ((0, -4.3, 0), (0, -1, 0)),
+            ((2.5, 2.5, 2.5), (0.500017643, 0.707081795, 0.500017643))]
+    for p, want in gold:
+        assert np.array_equal(d2.normal(*map(float, p)), np.array(want, dtype=np.float32))
+
+
+def test_lattice_64_over_pm5(d2):
+    xs = (-5 + 10 * np.arange(64) / 64).astype(np.float32)
+    pts = np.stack(np.meshgrid(xs, xs, xs, indexing="ij"), -1).reshape(-1, 3)
+    s = d2.eval_sdf(pts)
+    assert int((s < 0).sum()) == 6089
+    assert abs(float(s.astype(np.float64).sum()) - 180174.036465) < 1e-5
+
+
+def test_builtin_bank_matches_compiled_scene_cl(oracle):
+    """The oracle's C restatement of sd0..sd4 against the literal OpenCL text compiled for the host."""
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-4, 4, (20000, 3)).astype(np.float32)
+    a = oracle.Scene.from_dir(scene_dir("flat256"), use_scene_cl=False).eval_sdf(pts)
+    b = oracle.Scene.from_dir(scene_dir("flat256"), use_scene_cl=True).eval_sdf(pts)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,center,diameter,interior", [
+    ("sphere", [0.0, 0.0, 0.0], 5.3515625, 1376312),
+    ("design2", [0.0, -0.0390625, 0.0], 9.3359375, 692566),
+    ("design1", [0.0, 0.0, 0.0], 6.6796875, 2868560)])
+def test_stage_a_bounding_box(oracle, name, center, diameter, interior):
+    c, d, n = oracle.Scene.from_dir(scene_dir(name)).estimate_bounding_box(10.0)
+    assert (c, d, n) == (center, [diameter] * 3, interior)
+
+
+GOLD_128 = {  # levels 4/6/7, retopo = identity, GD 50
+    "sphere": dict(tris=33608, levels={5: 48, 6: 33560}, sum_abs=252060.0004, sums=None),
+    "design2": dict(tris=22916, levels={5: 50, 6: 22866}, sum_abs=232432.913903,
+                    sums=(-905.326588, -54517.600834, 887.786322)),
+    "design1": dict(tris=33752, levels={4: 48, 6: 33704}, sum_abs=321722.736987,
+                    sums=(-20.972755, -45.163625, -20.972766)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GOLD_128))
+def test_pipeline_128(oracle, lookup_table, name):
+    g = GOLD_128[name]
+    sc = oracle.Scene.from_dir(scene_dir(name))
+    cfg = oracle.parse_export_config(export_config_text(name, levels=(4, 6, 7), gd=50))
+    c, d, _ = sc.estimate_bounding_box(cfg.bounding_box_half_diameter)
+    tris, st = sc.get_surface(c, d[0], cfg, lookup_table)
+    assert len(tris) == g["tris"]
+    assert {l: int(st.triangles[l]) for l in range(32) if st.triangles[l]} == g["levels"]
+    v = sc.gradient_descent(tris, 50).reshape(-1, 3).astype(np.float64)
+    assert not np.isnan(v).any()
+    assert abs(np.linalg.norm(v, axis=1).sum() - g["sum_abs"]) < 5e-4
+    if g["sums"]:
+        assert np.allclose(v.sum(0), g["sums"], rtol=0, atol=2e-6)
+
+
+def test_sphere_mean_radius(oracle, lookup_table):
+    sc = oracle.Scene.from_dir(scene_dir("sphere"))
+    cfg = oracle.parse_export_config(export_config_text("sphere", levels=(4, 6, 7)))
+    c, d, _ = sc.estimate_bounding_box(cfg.bounding_box_half_diameter)
+    tris, _ = sc.get_surface(c, d[0], cfg, lookup_table)
+    v = sc.gradient_descent(tris, 50).reshape(-1, 3).astype(np.float64)
+    assert abs(np.linalg.norm(v, axis=1).mean() - 2.5) < 1e-6  # world radius 0.5 * root scale 5
+
+
+def test_lookup_table(oracle, lookup_table):
+    assert lookup_table.total == 820 and lookup_table.count.max() == 5
+    assert lookup_table.count[0] == 0 and lookup_table.count[255] == 0
+    assert lookup_table.tris[1, 0].tolist() == [0, 3, 8]
+    # an odd 5-loop "2,3,8,9,10" -> (l0,l1,l_last) then the strip over the rest (geometry.hpp:228-248)
+    assert lookup_table.tris[7, :3].tolist() == [[2, 3, 10], [3, 8, 9], [9, 10, 3]]
+
+
+def test_lattice_indexing_round_trip(oracle):
+    c, d, res = [0.0, -0.0390625, 0.0], 9.3359375, 512
+    rng = np.random.default_rng(2)
+    for ix, iy, iz in rng.integers(0, res + 1, (200, 3)):
+        p = oracle.lattice_point(c, d, res, int(ix), int(iy), int(iz))
+        assert oracle.lattice_coords(c, d, res, p).tolist() == [ix, iy, iz]
+    # snapping truncates toward zero (ISV.hpp:91-96)
+    step = np.float32(d) / np.float32(res)
+    p = oracle.lattice_point(c, d, res, 10, 20, 30) + np.float32(0.75) * step
+    assert oracle.lattice_coords(c, d, res, p).tolist() == [10, 20, 30]
+
+
+def test_big_config_goldens_match_survey():
+    """tests/golden/big_configs.json (oracle runs at 512^3 / 1024^3) against SURVEY.md 8(c)."""
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "big_configs.json")))
+    assert g["sphere_6_8_9"]["triangles"] == 539288
+    assert abs(g["sphere_6_8_9"]["gd50_sum_abs"] - 4044660.047081) < 1e-4
+    assert np.allclose(g["sphere_6_8_9"]["gd50_sums"], (-66.030199, -149.687263, -66.030195), atol=2e-6)
+    assert g["design2_6_8_9"]["triangles"] == 395668
+    assert np.allclose(g["design2_6_8_9"]["gd50_sums"], (-19295.482374, -886969.324338, 18531.609296), atol=2e-5)
+    assert abs(g["design2_6_8_9"]["gd50_sum_abs"] - 3991366.384922) < 1e-4
+    assert g["design2_7_9_10"]["triangles"] == 1599420
+    assert g["design2_7_9_10"]["per_level"] == {"7": 798, "8": 6133, "9": 1592489}
+    assert np.allclose(g["design2_7_9_10"]["gd50_sums"], (-77981.315318, -3517190.860812, 78373.765844), atol=2e-4)
