@@ -63,7 +63,7 @@ def build(verbose=False, prebuild_scenes=True):
         _run([HIPCC] + DEVICE_FLAGS + ["-fgpu-rdc", "-emit-llvm", "-DDCSG_EXTERN_BANK", "-c", kernels, "-o", bc])
 
     _embed_cl()
-    host_src = [os.path.join(CSRC, f) for f in ("dcsg_api.cpp", "scene.cpp", "jit.cpp")]
+    host_src = [os.path.join(CSRC, f) for f in ("dcsg_api.cpp", "scene.cpp", "jit.cpp", "specialise.cpp")]
     host_deps = host_src + glob.glob(os.path.join(CSRC, "*.h*")) + \
         [os.path.join(OUT, "embedded_cl.inc"), os.path.join(HERE, "..", "include", "dcsg.h")]
     if _newer(LIB, host_deps):
@@ -77,19 +77,25 @@ def build(verbose=False, prebuild_scenes=True):
 
 
 def prebuild_jit_cache(verbose=False):
-    """Compile the fixture scenes' scene.cl into the JIT cache (no GPU needed)."""
+    """Compile the code objects the fixture scenes need (brush text + specialised build procedure, and the
+    un-specialised variant the interpreter tests use) into the JIT cache.  No GPU needed."""
     lib = ctypes.CDLL(LIB)
-    lib.dcsg_jit_prebuild.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
-                                      ctypes.POINTER(ctypes.c_int)]
+    lib.dcsg_jit_prebuild_scene.argtypes = [ctypes.c_char_p] * 4 + [ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
     scenes = sorted(glob.glob(os.path.join(HERE, "..", "tests", "golden", "scenes", "*", "scene.cl")))
     for path in scenes:
-        log = ctypes.create_string_buffer(1 << 16)
-        cached = ctypes.c_int(0)
-        rc = lib.dcsg_jit_prebuild(open(path, "rb").read(), log, len(log), ctypes.byref(cached))
-        if rc != 0:
-            raise RuntimeError("JIT of %s failed:\n%s" % (path, log.value.decode(errors="replace")))
-        if verbose:
-            print("jit", os.path.relpath(path), "cached" if cached.value else "compiled")
+        d = os.path.dirname(path)
+        rd = lambda n: open(os.path.join(d, n), "rb").read()
+        for spec in ("48", "0"):
+            os.environ["DCSG_SPECIALISE"] = spec
+            log = ctypes.create_string_buffer(1 << 16)
+            cached = ctypes.c_int(0)
+            rc = lib.dcsg_jit_prebuild_scene(rd("scene.txt"), rd("buildprocedure.txt"), rd("scene.cl"), log, len(log),
+                                             ctypes.byref(cached))
+            if rc != 0:
+                raise RuntimeError("JIT of %s failed:\n%s" % (path, log.value.decode(errors="replace")))
+            if verbose:
+                print("jit", os.path.relpath(d), "specialise<=" + spec, "cached" if cached.value else "compiled")
+    os.environ.pop("DCSG_SPECIALISE", None)
 
 
 if __name__ == "__main__":

@@ -28,10 +28,11 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-// Interpreter variants of the evaluation kernels (kernels.hip): [0] generic (register program, stack in
-// LDS, any program), [1] / [2] stack program with a register-resident stack of depth <= 4 / <= 8.
+// Variants of the evaluation kernels (kernels.hip): [0] generic interpreter (register program, stack in
+// LDS, any program), [1] / [2] stack-program interpreter with a register-resident stack of depth <= 4 / <= 8,
+// [3] per-scene specialised code (scene modules only).
 struct Kernels {
-    hipFunction_t sweep[3] = {}, eval_points[3] = {}, bbox[3] = {}, project[3] = {};
+    hipFunction_t sweep[4] = {}, eval_points[4] = {}, bbox[4] = {}, project[4] = {};
     hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr;
 };
 
@@ -52,7 +53,7 @@ struct dcsg_ctx {
     hipModule_t builtin_mod = nullptr, scene_mod = nullptr;
     Kernels kb, ks;       // built-in bank / scene module
     Kernels* k = nullptr;  // active
-    bool scene_loaded = false, jit = false;
+    bool scene_loaded = false, jit = false, specialised = false;
     int variant = 0;  // index into Kernels::sweep[] etc., chosen from the scene's register count
     Scene scene;
     std::vector<float> ad_host;
@@ -115,8 +116,8 @@ void release(DevBuf& b)
 
 int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
 {
-    static const char* suffix[3] = {"", "_s4", "_s8"};
-    for (int v = 0; v < 3; v++) {
+    static const char* suffix[4] = {"", "_s4", "_s8", "_sp"};
+    for (int v = 0; v < (scene_module ? 4 : 3); v++) {
         struct {
             const char* name;
             hipFunction_t* f;
@@ -167,6 +168,45 @@ unsigned sweep_grid(const dcsg_ctx* c, unsigned tiles)
 {
     unsigned cap = (unsigned)c->n_cu * 32u;  // 8 resident 256-thread blocks per CU, x4 for tail balance
     return tiles < cap ? tiles : cap;
+}
+
+// How a scene's code object is obtained: the stand-alone module with the HIP-native brush bank, or a
+// module compiled from its scene.cl (+ the generated specialisation of its build procedure).
+struct ModulePlan {
+    bool needs_jit = false, specialise = false, null0 = true;
+    std::string cl, extra;
+};
+
+bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std::string& err)
+{
+    p.cl = scene_cl ? scene_cl : "";
+    bool builtin_only;  // every brush in use is one of sd0..sd4 with its standard body
+    if (!scene_cl) {
+        if (s.max_brush_id > 4) {
+            err = "scene uses brush id " + std::to_string(s.max_brush_id) + " but no scene.cl was given";
+            return false;
+        }
+        builtin_only = true;
+    } else {
+        builtin_only = s.max_brush_id <= 4 && scene_cl_is_builtin_only(p.cl);
+    }
+    if (s.lds_bytes() > 160 * 1024) {
+        err = "scene tables need " + std::to_string(s.lds_bytes()) + " B of LDS (> 160 KiB)";
+        return false;
+    }
+    // Small stack-disciplined programs are specialised: the whole evaluation becomes straight-line code.
+    int n_evals = 0;
+    for (int k = 0; k < s.n_stack_prog; k++) n_evals += s.stack_prog[4 * k] <= 35 ? 1 : 0;
+    const char* env_spec = getenv("DCSG_SPECIALISE");  // max object evaluations to specialise; 0 disables
+    int spec_limit = env_spec ? atoi(env_spec) : 48;
+    p.specialise = s.n_stack_prog > 0 && n_evals <= spec_limit;
+    p.needs_jit = !(builtin_only && !p.specialise);
+    if (p.needs_jit) {
+        if (builtin_only) p.cl = builtin_scene_cl();
+        p.null0 = builtin_only || scene_cl_null_brush_is_const(p.cl);
+        p.extra = specialised_source(s, p.null0, p.specialise);
+    }
+    return true;
 }
 
 int need_scene(dcsg_ctx* c)
@@ -369,25 +409,15 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     Scene s;
     std::string err;
     if (!parse_scene(scene_txt, bp_txt, s, err)) return fail(c, DCSG_ERR_INVALID, err);
-    bool builtin;
-    std::string cl = scene_cl ? scene_cl : "";
-    if (!scene_cl) {
-        if (s.max_brush_id > 4)
-            return fail(c, DCSG_ERR_INVALID,
-                        "scene uses brush id " + std::to_string(s.max_brush_id) + " but no scene.cl was given");
-        builtin = true;
-    } else {
-        builtin = s.max_brush_id <= 4 && scene_cl_is_builtin_only(cl);
-    }
-    if (s.lds_bytes() > 160 * 1024)
-        return fail(c, DCSG_ERR_INVALID, "scene tables need " + std::to_string(s.lds_bytes()) + " B of LDS (> 160 KiB)");
-    if (builtin) {
+    ModulePlan plan;
+    if (!plan_scene_module(s, scene_cl, plan, err)) return fail(c, DCSG_ERR_INVALID, err);
+    if (!plan.needs_jit) {
         build_blob(s, true);
         c->k = &c->kb;
         c->jit = false;
     } else {
         std::string hsaco, log;
-        if (!jit_scene_module(cl, hsaco, log, nullptr))
+        if (!jit_scene_module(plan.cl, plan.extra, hsaco, log, nullptr))
             return fail(c, DCSG_ERR_BUILD, "Error when building evaluation program:\n" + log);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->scene_mod) {
@@ -397,19 +427,20 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
         HIPCHK(c, hipModuleLoadData(&c->scene_mod, hsaco.data()));
         int r = load_kernels(c, c->scene_mod, c->ks, true);
         if (r) return r;
-        build_blob(s, scene_cl_null_brush_is_const(cl));
+        build_blob(s, plan.null0);
         c->k = &c->ks;
         c->jit = true;
     }
+    c->specialised = c->jit && plan.specialise;
     int r = ensure(c, c->d_blob, s.blob.size() * 4);
     if (r) return r;
     HIPCHK(c, hipMemcpy(c->d_blob.p, s.blob.data(), s.blob.size() * 4, hipMemcpyHostToDevice));
     c->scene = std::move(s);
     const int depth = c->scene.n_stack_prog ? c->scene.stack_depth : 1000;
-    c->variant = depth <= 4 ? 1 : (depth <= 8 ? 2 : 0);
+    c->variant = c->specialised ? 3 : (depth <= 4 ? 1 : (depth <= 8 ? 2 : 0));
     if (const char* force = getenv("DCSG_FORCE_VARIANT")) {  // A/B testing only; never exceeds what the program fits
         int f = atoi(force);
-        if (f == 0 || (f == 2 && depth <= 8)) c->variant = f;
+        if (f == 0 || (f == 1 && depth <= 4) || (f == 2 && depth <= 8)) c->variant = f;
     }
     c->scene_loaded = true;
     c->n_tris = 0;
@@ -776,6 +807,28 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
     size_t w = fwrite(buf.data(), 1, bytes, f);
     int ok = fclose(f) == 0 && w == bytes;
     return ok ? 0 : DCSG_ERR_IO;
+}
+
+int dcsg_jit_prebuild_scene(const char* scene_txt, const char* bp_txt, const char* scene_cl, char* log_out, size_t log_cap,
+                             int* from_cache)
+{
+    Scene s;
+    std::string err, hsaco, log;
+    ModulePlan plan;
+    bool cached = false;
+    int rc = 0;
+    if (!parse_scene(scene_txt, bp_txt, s, err) || !plan_scene_module(s, scene_cl, plan, err)) {
+        log = err;
+        rc = DCSG_ERR_INVALID;
+    } else if (plan.needs_jit && !jit_scene_module(plan.cl, plan.extra, hsaco, log, &cached)) {
+        rc = DCSG_ERR_BUILD;
+    }
+    if (from_cache) *from_cache = cached ? 1 : 0;
+    if (log_out && log_cap) {
+        strncpy(log_out, log.c_str(), log_cap - 1);
+        log_out[log_cap - 1] = '\0';
+    }
+    return rc;
 }
 
 int dcsg_compile_program(const char* scene_txt, const char* bp_txt, int32_t* reg_prog, int* n_reg_steps, int* n_regs,

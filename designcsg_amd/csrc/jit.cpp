@@ -215,7 +215,8 @@ static bool run_action(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, 
     return true;
 }
 
-bool jit_scene_module(const std::string& scene_cl, std::string& hsaco, std::string& log, bool* from_cache)
+bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, std::string& hsaco, std::string& log,
+                      bool* from_cache)
 {
     if (from_cache) *from_cache = false;
     std::string kernels_bc;
@@ -224,7 +225,7 @@ bool jit_scene_module(const std::string& scene_cl, std::string& hsaco, std::stri
         log = "cannot read " + bc_path + " (run __graft_entry__.build())";
         return false;
     }
-    std::string source = std::string(kScenePrelude) + scene_cl + kSceneEpilogue;
+    std::string source = std::string(kScenePrelude) + scene_cl + kSceneEpilogue + extra_cl;
 
     uint64_t h1 = fnv1a64(source.data(), source.size(), 0xcbf29ce484222325ull);
     h1 = fnv1a64(kernels_bc.data(), kernels_bc.size(), h1);
@@ -285,7 +286,9 @@ extern "C" int dcsg_jit_prebuild(const char* scene_cl, char* log_out, size_t log
 {
     std::string hsaco, log;
     bool cached = false;
-    bool ok = dcsg::jit_scene_module(scene_cl ? scene_cl : "", hsaco, log, &cached);
+    dcsg::Scene none;
+    bool ok = dcsg::jit_scene_module(scene_cl ? scene_cl : "", dcsg::specialised_source(none, false, false), hsaco, log,
+                                     &cached);
     if (from_cache) *from_cache = cached ? 1 : 0;
     if (log_out && log_cap) {
         strncpy(log_out, log.c_str(), log_cap - 1);

@@ -8,5 +8,7 @@ bool read_file(const std::string& path, std::string& out);
 // scene_cl: the generated scene.cl text.  On success hsaco holds a gfx950 code object containing
 // every kernel of kernels.hip linked against the scene's sdf_bank.  On failure log holds the
 // compiler diagnostics (what Evaluator::build returns as the build log, Evaluator.cpp:64-89).
-bool jit_scene_module(const std::string& scene_cl, std::string& hsaco, std::string& log, bool* from_cache);
+// extra_cl: generated OpenCL C appended after the epilogue (csrc/specialise.cpp).
+bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, std::string& hsaco, std::string& log,
+                      bool* from_cache);
 }  // namespace dcsg

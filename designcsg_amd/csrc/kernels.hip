@@ -50,6 +50,14 @@ __device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_
     dcsg_cl_float3 v = {x, y, z};
     return sdf_bank(v, (unsigned char)shape_id);
 }
+// Per-scene specialisation (csrc/specialise.cpp): the scene's stack program emitted as straight-line
+// OpenCL C next to the brush text -- object constants as literals, one variable per stack level and
+// stencil point -- for 7 points (elements 0..6 of the float8s) and for 1 point.  Same arithmetic in the same
+// order as the interpreters, so the results are bit-identical; no decode, no tables, no LDS.
+typedef float dcsg_cl_float8 __attribute__((ext_vector_type(8)));
+extern "C" __device__ dcsg_cl_float8 dcsg_spec_eval7(dcsg_cl_float8 px, dcsg_cl_float8 py, dcsg_cl_float8 pz);
+extern "C" __device__ float dcsg_spec_eval1(float x, float y, float z);
+#define DCSG_HAVE_SPEC 1
 #else
 // OpenCL max(gentype x, gentype y): y if x < y, otherwise x
 __device__ __forceinline__ float cl_max_f(float x, float y) { return x < y ? y : x; }
@@ -421,6 +429,42 @@ __device__ __forceinline__ void dcsg_stencil(const SceneLds& s, float x, float y
     dcsg_finish_normal(o[1] - o[2], o[3] - o[4], o[5] - o[6], nx, ny, nz);
 }
 
+#ifdef DCSG_HAVE_SPEC
+// Out-of-line copy for waves that hold a -0.0 coordinate (exact "+ 0.0f" stencil, no shared values).
+__device__ __noinline__ dcsg_cl_float8 dcsg_spec_eval7_exact(dcsg_cl_float8 px, dcsg_cl_float8 py, dcsg_cl_float8 pz)
+{
+    return dcsg_spec_eval7(px, py, pz);
+}
+
+// dcsg_stencil for the specialised scene module (K = -1 in the kernel bodies below).
+__device__ __forceinline__ void dcsg_stencil_spec(float x, float y, float z, bool want_sdf, bool want_normal, float& sdf,
+                                                  float& nx, float& ny, float& nz)
+{
+    if (!want_normal) {
+        sdf = dcsg_spec_eval1(x, y, z);
+        return;
+    }
+    const float e = (float)K2_NORMAL_EPSILON;
+    float xp = x + e, xm = x - e, yp = y + e, ym = y - e, zp = z + e, zm = z - e;
+    bool nzero = dcsg_is_neg_zero(x) || dcsg_is_neg_zero(y) || dcsg_is_neg_zero(z);
+    dcsg_cl_float8 o;
+    if (__builtin_amdgcn_ballot_w64(nzero) != 0ull) {
+        const float zero = 0.0f;  // v+dx adds +0.0 on the other axes, v-dx subtracts it (k2.cl:167-173)
+        dcsg_cl_float8 px = {x, xp, xm, x + zero, x - zero, x + zero, x - zero, 0.0f};
+        dcsg_cl_float8 py = {y, y + zero, y - zero, yp, ym, y + zero, y - zero, 0.0f};
+        dcsg_cl_float8 pz = {z, z + zero, z - zero, z + zero, z - zero, zp, zm, 0.0f};
+        o = dcsg_spec_eval7_exact(px, py, pz);
+    } else {
+        dcsg_cl_float8 px = {x, xp, xm, x, x, x, x, 0.0f};
+        dcsg_cl_float8 py = {y, y, y, yp, ym, y, y, 0.0f};
+        dcsg_cl_float8 pz = {z, z, z, z, z, zp, zm, 0.0f};
+        o = dcsg_spec_eval7(px, py, pz);
+    }
+    sdf = o[0];
+    dcsg_finish_normal(o[1] - o[2], o[3] - o[4], o[5] - o[6], nx, ny, nz);
+}
+#endif
+
 // ISV3D64::getPoint, ISV.hpp:103-109
 __device__ __forceinline__ float dcsg_lattice_coord(const DcsgLattice& L, int axis, int i)
 {
@@ -477,8 +521,12 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
         if (K == 0) {
             if (sdf_out) sd = dcsg_primary_sdf(s, x, y, z);
             if (nrm_out) dcsg_get_normal(s, x, y, z, nx, ny, nz);
+#ifdef DCSG_HAVE_SPEC
+        } else if (K < 0) {
+            dcsg_stencil_spec(x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
+#endif
         } else {
-            dcsg_stencil<(K == 0 ? 4 : K)>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
+            dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
         }
         if (sdf_out) sdf_out[idx] = sd;
         if (nrm_out) {
@@ -500,6 +548,9 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
 DCSG_SWEEP_KERNEL(dcsg_sweep, 0)
 DCSG_SWEEP_KERNEL(dcsg_sweep_s4, 4)
 DCSG_SWEEP_KERNEL(dcsg_sweep_s8, 8)
+#ifdef DCSG_HAVE_SPEC
+DCSG_SWEEP_KERNEL(dcsg_sweep_sp, -1)
+#endif
 
 // ---------------------------------------------------------------------------
 // Kernel 2: k2-equivalent point evaluation (Evaluator::eval_sdf_at_points /
@@ -520,8 +571,12 @@ __device__ __forceinline__ void dcsg_eval_points_body(const uint4* __restrict__ 
         if (K == 0) {
             if (mode == 0) sd = dcsg_primary_sdf(s, x, y, z);
             else dcsg_get_normal(s, x, y, z, nx, ny, nz);
+#ifdef DCSG_HAVE_SPEC
+        } else if (K < 0) {
+            dcsg_stencil_spec(x, y, z, mode == 0, mode != 0, sd, nx, ny, nz);
+#endif
         } else {
-            dcsg_stencil<(K == 0 ? 4 : K)>(s, x, y, z, mode == 0, mode != 0, sd, nx, ny, nz);
+            dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, mode == 0, mode != 0, sd, nx, ny, nz);
         }
         if (mode == 0) {
             out[i] = sd;
@@ -543,6 +598,9 @@ __device__ __forceinline__ void dcsg_eval_points_body(const uint4* __restrict__ 
 DCSG_EVAL_KERNEL(dcsg_eval_points, 0)
 DCSG_EVAL_KERNEL(dcsg_eval_points_s4, 4)
 DCSG_EVAL_KERNEL(dcsg_eval_points_s8, 8)
+#ifdef DCSG_HAVE_SPEC
+DCSG_EVAL_KERNEL(dcsg_eval_points_sp, -1)
+#endif
 
 // ---------------------------------------------------------------------------
 // wave / block reductions and scans
@@ -604,7 +662,10 @@ __device__ __forceinline__ void dcsg_bbox_body(const uint4* __restrict__ blob, i
         float z = half_neg + cd * (float)iz;
         float v, u0, u1, u2;
         if (K == 0) v = dcsg_primary_sdf(s, x, y, z);
-        else dcsg_stencil<(K == 0 ? 4 : K)>(s, x, y, z, true, false, v, u0, u1, u2);
+#ifdef DCSG_HAVE_SPEC
+        else if (K < 0) v = dcsg_spec_eval1(x, y, z);
+#endif
+        else dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, true, false, v, u0, u1, u2);
         if ((double)v < bb_eps) {  // "p.second < BB_EPSILON", float vs double
             cnt++;
             mn[0] = ix < mn[0] ? ix : mn[0];
@@ -639,6 +700,9 @@ __device__ __forceinline__ void dcsg_bbox_body(const uint4* __restrict__ blob, i
 DCSG_BBOX_KERNEL(dcsg_bbox, 0)
 DCSG_BBOX_KERNEL(dcsg_bbox_s4, 4)
 DCSG_BBOX_KERNEL(dcsg_bbox_s8, 8)
+#ifdef DCSG_HAVE_SPEC
+DCSG_BBOX_KERNEL(dcsg_bbox_sp, -1)
+#endif
 
 // ---------------------------------------------------------------------------
 // Mesher (Mesh::getSurface, mesh.hpp:148-311) on the dense lattice.
@@ -958,8 +1022,12 @@ __device__ __forceinline__ void dcsg_project_body(const uint4* __restrict__ blob
             if (K == 0) {
                 sd = dcsg_primary_sdf(s, x, y, z);
                 dcsg_get_normal(s, x, y, z, nx, ny, nz);
+#ifdef DCSG_HAVE_SPEC
+            } else if (K < 0) {
+                dcsg_stencil_spec(x, y, z, true, true, sd, nx, ny, nz);
+#endif
             } else {
-                dcsg_stencil<(K == 0 ? 4 : K)>(s, x, y, z, true, true, sd, nx, ny, nz);
+                dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, true, true, sd, nx, ny, nz);
             }
             float m = -sd;  // v3f_scale(n, -s) then v3f_add, CVector.cpp:128-149
             x = x + m * nx;
@@ -981,6 +1049,9 @@ __device__ __forceinline__ void dcsg_project_body(const uint4* __restrict__ blob
 DCSG_PROJECT_KERNEL(dcsg_project, 0)
 DCSG_PROJECT_KERNEL(dcsg_project_s4, 4)
 DCSG_PROJECT_KERNEL(dcsg_project_s8, 8)
+#ifdef DCSG_HAVE_SPEC
+DCSG_PROJECT_KERNEL(dcsg_project_sp, -1)
+#endif
 
 #ifdef DCSG_EXTERN_BANK
 // Points the scene module's program-scope `arbitrary_data` (k2.cl:41,251) at the uploaded table.

@@ -53,6 +53,10 @@ bool parse_lookup_table(const char* text, std::vector<uint8_t>& table, int& tota
 // into one device-side compare.
 float angle_threshold_to_q_star(float threshold);
 
+// csrc/specialise.cpp
+std::string specialised_source(const Scene& s, bool null_brush_const, bool enable);
+const char* builtin_scene_cl();
+
 uint64_t fnv1a64(const void* data, size_t n, uint64_t seed);
 
 }  // namespace dcsg

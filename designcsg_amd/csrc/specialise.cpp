@@ -1,0 +1,124 @@
+// specialise.cpp -- emits a scene's stack program as straight-line OpenCL C (see kernels.hip,
+// "Per-scene specialisation").  The text is appended to the brush source before it goes through the
+// OpenCL C front-end, so the compiler sees the whole evaluation: constants fold into operands, the seven
+// stencil transforms share sub-expressions, nothing is interpreted.  Every expression is written in the
+// operand order of the interpreters (k2.cl:105-111 for the object transform, T_min/T_max as a<b?a:b), with
+// literals as exact hexadecimal floats, so results are bit-identical to them.
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "scene.hpp"
+
+namespace dcsg {
+
+static std::string hexf(float f)
+{
+    char buf[64];
+    if (f != f) return "NAN";
+    if (f - f != 0.0f) return f > 0 ? "INFINITY" : "(-INFINITY)";
+    snprintf(buf, sizeof(buf), "(%af)", (double)f);  // exact: hex float literal with f suffix
+    return buf;
+}
+
+static void emit_function(const Scene& s, bool null_brush_const, int N, std::string& out)
+{
+    enum { PUSH = 32, ACC_MIN = 33, ACC_MAX = 34, ACC_NEGMAX = 35, POP_MIN = 36, POP_MAX = 37, POP_NEGMAX = 38, EXPORT_TOP = 39 };
+    char line[512];
+    auto P = [&](const char* fmt, auto... a) {
+        snprintf(line, sizeof(line), fmt, a...);
+        out += line;
+    };
+    if (N == 7)
+        out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){\n";
+    else
+        out += "float dcsg_spec_eval1(float x, float y, float z){\n";
+    auto X = [&](int k) { return N == 7 ? "px.s" + std::to_string(k) : std::string("x"); };
+    auto Y = [&](int k) { return N == 7 ? "py.s" + std::to_string(k) : std::string("y"); };
+    auto Z = [&](int k) { return N == 7 ? "pz.s" + std::to_string(k) : std::string("z"); };
+    for (int k = 0; k < N; k++) P("  float o%d = (float)MAX_DISTANCE;\n", k);
+    for (int d = 0; d < (s.stack_depth > 0 ? s.stack_depth : 1); d++)
+        for (int k = 0; k < N; k++) P("  float s%d_%d = 0.0f;\n", d, k);
+    int tmp = 0;
+    for (int c = 0; c < s.n_stack_prog; c++) {
+        int op = s.stack_prog[4 * c], brush = s.stack_prog[4 * c + 1] & 0xff, obj = s.stack_prog[4 * c + 2],
+            depth = s.stack_prog[4 * c + 3];
+        if (op >= PUSH && op <= ACC_NEGMAX) {
+            int t = tmp++;
+            out += "  {\n";
+            if (brush == 0 && null_brush_const) {
+                for (int k = 0; k < N; k++) P("    const float r%d = (float)MAX_DISTANCE;\n", k);
+            } else {
+                const float* o = &s.pos[3 * obj];
+                const float* r = &s.right[3 * obj];
+                const float* u = &s.up[3 * obj];
+                const float* f = &s.fwd[3 * obj];
+                P("    const float ox=%s, oy=%s, oz=%s;\n", hexf(o[0]).c_str(), hexf(o[1]).c_str(), hexf(o[2]).c_str());
+                P("    const float rx=%s, ry=%s, rz=%s;\n", hexf(r[0]).c_str(), hexf(r[1]).c_str(), hexf(r[2]).c_str());
+                P("    const float ux=%s, uy=%s, uz=%s;\n", hexf(u[0]).c_str(), hexf(u[1]).c_str(), hexf(u[2]).c_str());
+                P("    const float fx=%s, fy=%s, fz=%s;\n", hexf(f[0]).c_str(), hexf(f[1]).c_str(), hexf(f[2]).c_str());
+                for (int k = 0; k < N; k++) {
+                    P("    const float dx%d = %s - ox, dy%d = %s - oy, dz%d = %s - oz;\n", k, X(k).c_str(), k, Y(k).c_str(), k,
+                      Z(k).c_str());
+                    P("    const float r%d = sdf_bank((float3)(dx%d*rx + dy%d*ry + dz%d*rz, dx%d*ux + dy%d*uy + dz%d*uz, "
+                      "dx%d*fx + dy%d*fy + dz%d*fz), (unsigned char)%d);\n",
+                      k, k, k, k, k, k, k, k, k, k, brush);
+                }
+            }
+            for (int k = 0; k < N; k++) {
+                if (op == PUSH) P("    s%d_%d = r%d;\n", depth, k, k);
+                else if (op == ACC_MIN) P("    s%d_%d = s%d_%d < r%d ? s%d_%d : r%d;\n", depth - 1, k, depth - 1, k, k, depth - 1, k, k);
+                else if (op == ACC_MAX) P("    s%d_%d = s%d_%d > r%d ? s%d_%d : r%d;\n", depth - 1, k, depth - 1, k, k, depth - 1, k, k);
+                else P("    { const float nb = -r%d; s%d_%d = s%d_%d > nb ? s%d_%d : nb; }\n", k, depth - 1, k, depth - 1, k, depth - 1, k);
+            }
+            out += "  }\n";
+            (void)t;
+        } else if (op >= POP_MIN && op <= POP_NEGMAX) {
+            for (int k = 0; k < N; k++) {
+                int a = depth - 2, b = depth - 1;
+                if (op == POP_MIN) P("  s%d_%d = s%d_%d < s%d_%d ? s%d_%d : s%d_%d;\n", a, k, a, k, b, k, a, k, b, k);
+                else if (op == POP_MAX) P("  s%d_%d = s%d_%d > s%d_%d ? s%d_%d : s%d_%d;\n", a, k, a, k, b, k, a, k, b, k);
+                else P("  { const float nb = -s%d_%d; s%d_%d = s%d_%d > nb ? s%d_%d : nb; }\n", b, k, a, k, a, k, a, k);
+            }
+        } else if (op == EXPORT_TOP) {
+            for (int k = 0; k < N; k++) P("  o%d = s%d_%d;\n", k, depth - 1, k);
+        }
+    }
+    if (N == 7)
+        out += "  return (float8)(o0, o1, o2, o3, o4, o5, o6, 0.0f);\n}\n";
+    else
+        out += "  return o0;\n}\n";
+}
+
+// OpenCL C for dcsg_spec_eval7 / dcsg_spec_eval1.  With `enable` false (or a program that is not
+// stack-disciplined) it emits stubs, which only satisfy the linker: the host never selects the
+// specialised kernels for such a scene.
+std::string specialised_source(const Scene& s, bool null_brush_const, bool enable)
+{
+    std::string out = "\n/* ---- generated by csrc/specialise.cpp ---- */\n";
+    if (!enable || s.n_stack_prog == 0) {
+        out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){ return (float8)(0.0f); }\n";
+        out += "float dcsg_spec_eval1(float x, float y, float z){ return 0.0f; }\n";
+        return out;
+    }
+    emit_function(s, null_brush_const, 7, out);
+    emit_function(s, null_brush_const, 1, out);
+    return out;
+}
+
+// The scene.cl the scene compiler writes for a design that defines no brushes of its own
+// (scenecompiler.py:424-425 + DesignCSG.py:9-22), reduced to what the export path needs.
+const char* builtin_scene_cl()
+{
+    return "float sd0( float3 v){ return MAX_DISTANCE; }\n"
+           "float sd1( float3 v){ return 0.0; }\n"
+           "float sd2( float3 v){ return length(v)-0.5; }\n"
+           "float sd3( float3 v){ v=fabs(v); float x = length((float2)(v.x,v.z)); float y = v.y; return max(x-0.5,y-0.5); }\n"
+           "float sd4( float3 v){ v=fabs(v); return max(v.x-0.5,max(v.y-0.5,v.z-0.5)); }\n"
+           "float sdf_bank(float3 v, unsigned char shape_id){\n"
+           "  switch(shape_id){ case 0: return sd0(v); case 1: return sd1(v); case 2: return sd2(v);\n"
+           "                    case 3: return sd3(v); case 4: return sd4(v); }\n"
+           "  return 0.0;\n}\n";
+}
+
+}  // namespace dcsg

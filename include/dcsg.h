@@ -93,7 +93,8 @@ int dcsg_load_scene(dcsg_ctx* ctx, const char* scene_txt, const char* buildproce
 int dcsg_set_arbitrary_data(dcsg_ctx* ctx, const float* data, size_t items);
 /* Scene facts after loading: object / build-step counts, interpreter registers in use, whether scene.cl
  * was compiled (1) or the HIP-native brush bank applies (0), which interpreter runs the evaluation
- * kernels (0 generic LDS stack, 1 register stack depth <= 4, 2 depth <= 8) and the program's stack depth
+ * kernels (0 generic LDS stack, 1 register stack depth <= 4, 2 depth <= 8, 3 per-scene specialised code)
+ * and the program's stack depth
  * (0 when it is not stack-disciplined).  Any out pointer may be NULL. */
 int dcsg_scene_info(const dcsg_ctx* ctx, int* n_objects, int* n_steps, int* n_slots, int* jit_compiled,
                     int* interpreter, int* stack_depth);
@@ -171,6 +172,10 @@ int dcsg_expand_lookup_table(const char* lookup_table_txt, uint8_t table[4096], 
  * object cache (used at install time so that known scenes load without compiling).  The compiler
  * log is copied to log_out; *from_cache = 1 when the code object already existed. */
 int dcsg_jit_prebuild(const char* scene_cl, char* log_out, size_t log_cap, int* from_cache);
+/* Same for a whole scene: compiles exactly the code object dcsg_load_scene would ask for (brush text plus
+ * the specialisation of its build procedure), if it needs one. */
+int dcsg_jit_prebuild_scene(const char* scene_txt, const char* buildprocedure_txt, const char* scene_cl, char* log_out,
+                            size_t log_cap, int* from_cache);
 
 #ifdef __cplusplus
 }

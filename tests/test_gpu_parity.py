@@ -43,17 +43,25 @@ def sorted_tris(t):
 EXPECTED_STACK_DEPTH = {"sphere": 1, "design1": 1, "design2": 1, "flat256": 1, "mixed_groups": 2, "grouped256": 2}
 
 
-@pytest.mark.parametrize("interpreter", ["auto", "generic"])
+SPECIALISED = {"sphere", "design1", "design2", "mixed_groups"}  # <= 48 object evaluations
+
+
+@pytest.mark.parametrize("interpreter", ["auto", "stack", "generic"])
 @pytest.mark.parametrize("name", ALL_SCENES)
 def test_point_eval_bit_exact(ev, oracle, name, interpreter, monkeypatch):
-    """Both device interpreters (register-stack program / generic LDS-stack program) against the oracle,
-    which runs the build procedure exactly as buildprocedure.txt states it."""
+    """Every device evaluation path -- per-scene specialised code, the register-stack interpreter of the
+    stack program, the generic LDS-stack interpreter of the register program -- against the oracle, which
+    runs the build procedure exactly as buildprocedure.txt states it."""
+    if interpreter == "stack":
+        monkeypatch.setenv("DCSG_SPECIALISE", "0")
     if interpreter == "generic":
+        monkeypatch.setenv("DCSG_SPECIALISE", "0")
         monkeypatch.setenv("DCSG_FORCE_VARIANT", "0")
     load(ev, name)
     info = ev.scene_info()
     assert info["stack_depth"] == EXPECTED_STACK_DEPTH[name]
-    assert info["interpreter"] == (0 if interpreter == "generic" else 1)
+    want_variant = {"auto": 3 if name in SPECIALISED else 1, "stack": 1, "generic": 0}[interpreter]
+    assert info["interpreter"] == want_variant
     osc = oracle.Scene.from_dir(scene_dir(name))
     rng = np.random.default_rng(7)
     n = 200_000 if name in ("sphere", "design1", "design2") else 40_000
