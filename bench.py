@@ -73,6 +73,27 @@ def cpu_baseline(scene_dir, center, diameter, res, budget_s=15.0):
             "sample": "oracle fused SDF+normal on %d of %d lattice planes (%d points, %.1f s)" % (planes, n1, pts, dt)}
 
 
+KERNEL_VARIANT = {0: "dcsg_sweep", 1: "dcsg_sweep_s4", 2: "dcsg_sweep_s8", 3: "dcsg_sweep_sp"}
+
+
+def profiled_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed PMC summaries (profiles/<tag>_pmc_summary.json:
+    separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this same command, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950), taken from the newest profile of the same workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        tag = os.path.basename(f)[:-len("_pmc_summary.json")]
+        try:
+            b = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench.json")))
+            pmc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if b.get("config", {}).get("workload") == workload and kernel in pmc and "hbm_bytes_per_launch" in pmc[kernel]:
+            best = (pmc[kernel]["hbm_bytes_per_launch"]["total"], "profiles/" + os.path.basename(f))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +178,9 @@ def main():
     dt = float(t.item())
 
     if rank == 0:
+        kernel = KERNEL_VARIANT[ev.scene_info()["interpreter"]]
+        workload = ("%s scene, fused SDF+normal sweep of the %d^3 lattice (%d^3 voxels), box centre %s diameter %s"
+                    % (scene, n1, res, center, diameter))
         ms_per_step = dt / args.steps * 1e3
         value = res ** 3 * args.steps / dt / 1e6
         kernel_ms = sum(a.elapsed_time(b) for a, b in k_ev) / args.steps
@@ -167,15 +191,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s scene, fused SDF+normal sweep of the %d^3 lattice (%d^3 voxels), "
-                                   "box centre %s diameter %s" % (scene, n1, res, center, diameter),
+            "config": {"workload": workload,
                        "grid_level": grid_level, "parallelism": "z-slab x%d" % world,
                        "lattice_points": n1 ** 3},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "dcsg_sweep", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT * own_points},
         }
+        tr = profiled_traffic(kernel, workload) if world == 1 else None
+        if tr:
+            out["roofline"]["traffic"] = tr[0]
+            out["roofline"]["traffic_source"] = tr[1]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_dir, center, diameter, res)
         print(json.dumps(out))
