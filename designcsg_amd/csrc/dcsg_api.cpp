@@ -33,7 +33,7 @@ struct DevBuf {
 // [3] per-scene specialised code (scene modules only).
 struct Kernels {
     hipFunction_t sweep[4] = {}, eval_points[4] = {}, bbox[4] = {}, project[4] = {};
-    hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr;
+    hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr;
 };
 
 double now_s()
@@ -128,7 +128,8 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
     struct {
         const char* name;
         hipFunction_t* f;
-    } tab[] = {{"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan}, {"dcsg_mesh_emit", &k.emit}};
+    } tab[] = {{"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan}, {"dcsg_mesh_emit", &k.emit},
+               {"dcsg_test_sqrt", &k.test_sqrt}};
     for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
     if (scene_module) HIPCHK(c, hipModuleGetFunction(&k.set_ad, mod, "dcsg_set_arbitrary_data"));
     return 0;
@@ -807,6 +808,16 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
     size_t w = fwrite(buf.data(), 1, bytes, f);
     int ok = fclose(f) == 0 && w == bytes;
     return ok ? 0 : DCSG_ERR_IO;
+}
+
+int dcsg_debug_sqrt_device(dcsg_ctx* c, const float* d_in, size_t n, float* d_out, void* stream)
+{
+    if (!c || n > 0xffffff00ull) return DCSG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned cnt = (unsigned)n;
+    void* args[] = {(void*)&d_in, (void*)&d_out, &cnt};
+    hipFunction_t f = (c->scene_loaded && c->jit) ? c->ks.test_sqrt : c->kb.test_sqrt;
+    return launch(c, f, (unsigned)c->n_cu * 16u, DCSG_BLOCK, 0, (hipStream_t)stream, args);
 }
 
 int dcsg_jit_prebuild_scene(const char* scene_txt, const char* bp_txt, const char* scene_cl, char* log_out, size_t log_cap,

@@ -38,6 +38,27 @@
 #define OP_IDENTITY 5
 
 // ---------------------------------------------------------------------------
+// Correctly rounded sqrtf.  v_sqrt_f32 is good to 1 ulp; the IEEE result is obtained by testing the two
+// neighbours with exact FMA residuals -- the same fix-up the compiler emits for __builtin_sqrtf, which
+// additionally rescales inputs below 2^-96 (and patches 0 / inf) on every call.  Here a wave whose inputs
+// are all >= 2^-96 skips that scaffolding (9 instead of 15 VALU instructions; 8 square roots per lattice
+// point in the fused sweep); any other wave (tiny, zero, negative, NaN) takes the compiler's full sequence.
+// tests/test_gpu_parity.py::test_sqrt_all_float_inputs checks all 2^32 bit patterns against IEEE sqrtf.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dcsg_sqrt(float x)
+{
+    if (__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f)) != 0ull) return __builtin_sqrtf(x);
+    float r = __builtin_amdgcn_sqrtf(x);
+    float rm = __uint_as_float(__float_as_uint(r) - 1u);
+    float rp = __uint_as_float(__float_as_uint(r) + 1u);
+    float em = __builtin_fmaf(-rm, r, x);  // x - rm*r, exact sign
+    float ep = __builtin_fmaf(-rp, r, x);  // x - rp*r
+    r = 0.0f >= em ? rm : r;
+    r = 0.0f < ep ? rp : r;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
 // Brush bank
 // ---------------------------------------------------------------------------
 #ifdef DCSG_EXTERN_BANK
@@ -73,10 +94,10 @@ __device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_
     switch (shape_id & 0xff) {  // wave-uniform
     case 0: return (float)K2_MAX_DISTANCE;
     case 1: return 0.0f;
-    case 2: return __builtin_sqrtf(x * x + y * y + z * z) - 0.5f;
+    case 2: return dcsg_sqrt(x * x + y * y + z * z) - 0.5f;
     case 3: {
         float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
-        float r = __builtin_sqrtf(ax * ax + az * az);
+        float r = dcsg_sqrt(ax * ax + az * az);
         return cl_max_f(r - 0.5f, ay - 0.5f);
     }
     case 4: {
@@ -199,7 +220,7 @@ __device__ __forceinline__ float dcsg_primary_sdf(const SceneLds& s, float x, fl
 // OpenCL normalize(float3) pinned as v / length(v), zero vector stays zero.
 __device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
 {
-    float len = __builtin_sqrtf(x * x + y * y + z * z);
+    float len = dcsg_sqrt(x * x + y * y + z * z);
     if (len == 0.0f) {
         x = y = z = 0.0f;
     } else {
@@ -264,13 +285,13 @@ __device__ __forceinline__ void dcsg_bank_n(const float (&A)[N], const float (&B
         break;
     case 2:
 #pragma unroll
-        for (int k = 0; k < N; k++) r[k] = __builtin_sqrtf(A[k] * A[k] + B[k] * B[k] + C[k] * C[k]) - 0.5f;
+        for (int k = 0; k < N; k++) r[k] = dcsg_sqrt(A[k] * A[k] + B[k] * B[k] + C[k] * C[k]) - 0.5f;
         break;
     case 3:
 #pragma unroll
         for (int k = 0; k < N; k++) {
             float ax = __builtin_fabsf(A[k]), ay = __builtin_fabsf(B[k]), az = __builtin_fabsf(C[k]);
-            float rad = __builtin_sqrtf(ax * ax + az * az);
+            float rad = dcsg_sqrt(ax * ax + az * az);
             r[k] = cl_max_f(rad - 0.5f, ay - 0.5f);
         }
         break;
@@ -797,7 +818,7 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
         if (intersects) {
             // mesh.hpp:167-170
             float d = sample_sdf(S, c);
-            float mag = __builtin_sqrtf(P.hd[0] * P.hd[0] + P.hd[1] * P.hd[1] + P.hd[2] * P.hd[2]);
+            float mag = dcsg_sqrt(P.hd[0] * P.hd[0] + P.hd[1] * P.hd[1] + P.hd[2] * P.hd[2]);
             culled = __builtin_fabsf(d) > mag * 1.1f;
             if (!culled) {
                 // mesh.hpp:176-183
@@ -834,8 +855,8 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
                         dcsg_corner(dcsg_edge_b(e), 1.0f, c, P.hd, b);
                         sample_normal(S, a, na);
                         sample_normal(S, b, nb);
-                        float ma = __builtin_sqrtf(na[0] * na[0] + na[1] * na[1] + na[2] * na[2]);
-                        float mb = __builtin_sqrtf(nb[0] * nb[0] + nb[1] * nb[1] + nb[2] * nb[2]);
+                        float ma = dcsg_sqrt(na[0] * na[0] + na[1] * na[1] + na[2] * na[2]);
+                        float mb = dcsg_sqrt(nb[0] * nb[0] + nb[1] * nb[1] + nb[2] * nb[2]);
                         if (!(ma * mb < 1e-6f)) {
                             float q = (na[0] * nb[0] + na[1] * nb[1] + na[2] * nb[2]) / (ma * mb);
                             // (float)acos((double)q) > threshold, folded by the host into q_star
@@ -1052,6 +1073,13 @@ DCSG_PROJECT_KERNEL(dcsg_project_s8, 8)
 #ifdef DCSG_HAVE_SPEC
 DCSG_PROJECT_KERNEL(dcsg_project_sp, -1)
 #endif
+
+// Diagnostic: dcsg_sqrt over an array (exhaustive test of the custom square root).
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_test_sqrt(const float* __restrict__ in, float* __restrict__ out, unsigned int n)
+{
+    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < n; i += gridDim.x * DCSG_BLOCK) out[i] = dcsg_sqrt(in[i]);
+}
 
 #ifdef DCSG_EXTERN_BANK
 // Points the scene module's program-scope `arbitrary_data` (k2.cl:41,251) at the uploaded table.

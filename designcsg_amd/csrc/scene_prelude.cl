@@ -26,7 +26,20 @@ float sdf_bank(float3 v, unsigned char shape_id);
 float3 shader_bank(float3 gv, float3 lv, float3 n, unsigned char material_id);
 
 #define DCSG_OVL __attribute__((overloadable))
-float  DCSG_OVL sqrt(float x){ return __builtin_sqrtf(x); }
+/* Correctly rounded sqrtf: same sequence as dcsg_sqrt in kernels.hip (fast path for waves whose inputs are
+ * all >= 2^-96, the compiler's full IEEE expansion otherwise). */
+float dcsg_sqrt_ieee(float x){
+    if (__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f)) != 0ul) return __builtin_sqrtf(x);
+    float r = __builtin_amdgcn_sqrtf(x);
+    float rm = as_float(as_uint(r) - 1u);
+    float rp = as_float(as_uint(r) + 1u);
+    float em = __builtin_fmaf(-rm, r, x);
+    float ep = __builtin_fmaf(-rp, r, x);
+    r = 0.0f >= em ? rm : r;
+    r = 0.0f < ep ? rp : r;
+    return r;
+}
+float  DCSG_OVL sqrt(float x){ return dcsg_sqrt_ieee(x); }
 double DCSG_OVL sqrt(double x){ return __builtin_sqrt(x); }
 float  DCSG_OVL fabs(float x){ return __builtin_fabsf(x); }
 double DCSG_OVL fabs(double x){ return __builtin_fabs(x); }
@@ -37,9 +50,9 @@ float  DCSG_OVL dot(float2 a, float2 b){ return a.x*b.x+a.y*b.y; }
 float  DCSG_OVL dot(float3 a, float3 b){ return a.x*b.x+a.y*b.y+a.z*b.z; }
 float  DCSG_OVL dot(float4 a, float4 b){ return a.x*b.x+a.y*b.y+a.z*b.z+a.w*b.w; }
 float  DCSG_OVL length(float a){ return __builtin_fabsf(a); }
-float  DCSG_OVL length(float2 a){ return __builtin_sqrtf(a.x*a.x+a.y*a.y); }
-float  DCSG_OVL length(float3 a){ return __builtin_sqrtf(a.x*a.x+a.y*a.y+a.z*a.z); }
-float  DCSG_OVL length(float4 a){ return __builtin_sqrtf(a.x*a.x+a.y*a.y+a.z*a.z+a.w*a.w); }
+float  DCSG_OVL length(float2 a){ return dcsg_sqrt_ieee(a.x*a.x+a.y*a.y); }
+float  DCSG_OVL length(float3 a){ return dcsg_sqrt_ieee(a.x*a.x+a.y*a.y+a.z*a.z); }
+float  DCSG_OVL length(float4 a){ return dcsg_sqrt_ieee(a.x*a.x+a.y*a.y+a.z*a.z+a.w*a.w); }
 float  DCSG_OVL distance(float3 a, float3 b){ return length(a-b); }
 float3 DCSG_OVL normalize(float3 v){
     float l = length(v);

@@ -174,6 +174,9 @@ class Evaluator:
         self._ck(self._L.dcsg_copy_triangles_device(self._h, C.c_void_p(d_out), max_triangles,
                                                     C.c_void_p(stream or None)))
 
+    def debug_sqrt_device(self, d_in, n, d_out, stream=0):
+        self._ck(self._L.dcsg_debug_sqrt_device(self._h, C.c_void_p(d_in), n, C.c_void_p(d_out), C.c_void_p(stream or None)))
+
     def export(self, export_config_txt, stl_path=None, ply_path=None, dense_normals=False):
         """MyFrame::OnExportInner end to end on this GPU."""
         st = ExportStats()

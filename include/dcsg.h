@@ -168,6 +168,9 @@ int dcsg_compile_program(const char* scene_txt, const char* buildprocedure_txt, 
  * triangle (cms::getIndexTrianglesFromTable + getIndexTriangleStrip). */
 int dcsg_expand_lookup_table(const char* lookup_table_txt, uint8_t table[4096], int* total_triangles);
 
+/* Diagnostic: the kernels' correctly rounded square root over a device array (exhaustive GPU test). */
+int dcsg_debug_sqrt_device(dcsg_ctx* ctx, const float* d_in, size_t n, float* d_out, void* stream);
+
 /* The compile half of Evaluator::build without a device: compiles scene_cl into the on-disk code
  * object cache (used at install time so that known scenes load without compiling).  The compiler
  * log is copied to log_out; *from_cache = 1 when the code object already existed. */

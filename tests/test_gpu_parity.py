@@ -257,3 +257,32 @@ def test_jit_of_a_new_brush(ev, oracle, tmp_path):
     got, want = ev.eval_sdf_at_points(pts), osc.eval_sdf(pts)
     # sin() comes from the ROCm device library on the GPU and libm on the host: unpinned, 1e-6 abs
     assert np.max(np.abs(got - want)) <= 1e-6
+
+
+@pytest.mark.parametrize("module", ["builtin", "scene"])
+def test_sqrt_all_float_inputs(ev, module):
+    """The kernels' square root (fast path for waves whose inputs are all >= 2^-96, the compiler's IEEE sequence
+    otherwise) against IEEE sqrtf for EVERY binary32 bit pattern (builtin module) / every 8th (scene module)."""
+    import torch
+    if module == "scene":
+        load(ev, "design2")
+    else:
+        s = read_scene("flat256")
+        assert ev.build(s["scene.txt"], s["buildprocedure.txt"], None)[0] == 0 and not ev.scene_info()["jit"]
+    stream = torch.cuda.current_stream().cuda_stream
+    chunk = 1 << 26
+    step = 1 if module == "builtin" else 8
+    out = torch.empty(chunk, dtype=torch.float32, device="cuda")
+    for c in range(0, 1 << 32, chunk * step):
+        bits = torch.arange(c, c + chunk, dtype=torch.int64, device="cuda").to(torch.uint32 if hasattr(torch, "uint32") else torch.int64)
+        x = (torch.arange(c, c + chunk, dtype=torch.int64, device="cuda") - (1 << 32) * (c >= (1 << 31))).to(torch.int32).view(torch.float32)
+        ev.debug_sqrt_device(x.data_ptr(), chunk, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        xin = x.cpu().numpy()
+        with np.errstate(invalid="ignore"):
+            want = np.sqrt(xin)
+        got = out.cpu().numpy()
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(got), nan), hex(c)
+        assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32)), hex(c)
+        del bits
