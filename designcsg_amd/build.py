@@ -21,7 +21,9 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
 # numerics contract of kernels.hip: no contraction, IEEE divide/sqrt (hipcc default), no fast-math
-DEVICE_FLAGS = ["--offload-arch=" + ARCH, "--cuda-device-only", "-O3", "-ffp-contract=off", "-std=c++17"]
+# -fno-slp-vectorize: packed-f32 VALU ops are slower than the scalar pairs they replace on gfx950
+DEVICE_FLAGS = ["--offload-arch=" + ARCH, "--cuda-device-only", "-O3", "-ffp-contract=off", "-fno-slp-vectorize",
+                "-std=c++17"]
 LIB = os.path.join(OUT, "libdcsg_hip.so")
 
 

@@ -227,6 +227,21 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
     }
     std::string source = std::string(kScenePrelude) + scene_cl + kSceneEpilogue + extra_cl;
 
+    // Extra compiler options for experiments (';'-separated), e.g. DCSG_JIT_EXTRA_OPTS="-mllvm;-vectorize-slp=false".
+    // They take part in the cache key.
+    std::vector<std::string> extra_opts;
+    if (const char* e = getenv("DCSG_JIT_EXTRA_OPTS")) {
+        std::string t = e;
+        size_t i = 0;
+        while (i <= t.size()) {
+            size_t j = t.find(';', i);
+            std::string o = t.substr(i, j == std::string::npos ? std::string::npos : j - i);
+            if (!o.empty()) extra_opts.push_back(o);
+            if (j == std::string::npos) break;
+            i = j + 1;
+        }
+        for (auto& o : extra_opts) source += "\n// opt: " + o;
+    }
     uint64_t h1 = fnv1a64(source.data(), source.size(), 0xcbf29ce484222325ull);
     h1 = fnv1a64(kernels_bc.data(), kernels_bc.size(), h1);
     uint64_t h2 = fnv1a64(source.data(), source.size(), 0x84222325cbf29ce4ull);
@@ -250,8 +265,17 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
         log = "comgr: cannot create source data";
         return false;
     }
-    if (!run_action(AMD_COMGR_ACTION_COMPILE_SOURCE_WITH_DEVICE_LIBS_TO_BC, AMD_COMGR_LANGUAGE_OPENCL_2_0,
-                    {"-ffp-contract=off", "-cl-fp32-correctly-rounded-divide-sqrt", "-w", "-O3"}, src.s, bc.s, log))
+    // SLP vectorisation is off: on gfx950 the packed-f32 VALU ops it forms (v_pk_mul_f32 / v_pk_add_f32) issue
+    // slower than the scalar pairs they replace (measured: sphere sweep +15 %, Design2 +24 % with it off).
+    std::vector<const char*> cl_opts = {"-ffp-contract=off", "-cl-fp32-correctly-rounded-divide-sqrt", "-w", "-O3",
+                                        "-fno-slp-vectorize"};
+    std::vector<const char*> cg_opts = {"-O3", "-ffp-contract=off", "-fno-slp-vectorize"};
+    for (auto& o : extra_opts) {
+        cl_opts.push_back(o.c_str());
+        cg_opts.push_back(o.c_str());
+    }
+    if (!run_action(AMD_COMGR_ACTION_COMPILE_SOURCE_WITH_DEVICE_LIBS_TO_BC, AMD_COMGR_LANGUAGE_OPENCL_2_0, cl_opts, src.s,
+                    bc.s, log))
         return false;
     // 2. + the HIP kernels' bitcode
     if (!add_data(bc.s, AMD_COMGR_DATA_KIND_BC, "dcsg_kernels_extern.bc", kernels_bc)) {
@@ -265,8 +289,7 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
     }
     if (!run_action(AMD_COMGR_ACTION_LINK_BC_TO_BC, AMD_COMGR_LANGUAGE_NONE, {}, bc.s, linked.s, log)) return false;
     // 3. optimise across the seam (sdf_bank inlines into the interpreter) and emit ISA
-    if (!run_action(AMD_COMGR_ACTION_CODEGEN_BC_TO_RELOCATABLE, AMD_COMGR_LANGUAGE_NONE, {"-O3", "-ffp-contract=off"},
-                    linked.s, reloc.s, log))
+    if (!run_action(AMD_COMGR_ACTION_CODEGEN_BC_TO_RELOCATABLE, AMD_COMGR_LANGUAGE_NONE, cg_opts, linked.s, reloc.s, log))
         return false;
     if (!run_action(AMD_COMGR_ACTION_LINK_RELOCATABLE_TO_EXECUTABLE, AMD_COMGR_LANGUAGE_NONE, {}, reloc.s, exe.s, log))
         return false;
