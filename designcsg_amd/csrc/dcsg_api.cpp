@@ -34,6 +34,7 @@ struct DevBuf {
 struct Kernels {
     hipFunction_t sweep[4] = {}, eval_points[4] = {}, bbox[4] = {}, project[4] = {};
     hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr;
+    hipFunction_t sweep_sp2 = nullptr;  // specialised sweep, two planes per thread (scene modules only)
 };
 
 double now_s()
@@ -131,7 +132,10 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
     } tab[] = {{"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan}, {"dcsg_mesh_emit", &k.emit},
                {"dcsg_test_sqrt", &k.test_sqrt}};
     for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
-    if (scene_module) HIPCHK(c, hipModuleGetFunction(&k.set_ad, mod, "dcsg_set_arbitrary_data"));
+    if (scene_module) {
+        HIPCHK(c, hipModuleGetFunction(&k.set_ad, mod, "dcsg_set_arbitrary_data"));
+        HIPCHK(c, hipModuleGetFunction(&k.sweep_sp2, mod, "dcsg_sweep_sp2"));
+    }
     return 0;
 }
 
@@ -270,13 +274,20 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     const void* blob = c->d_blob.p;
     int nv = c->scene.blob_vec4();
     if (time_it) HIPCHK(c, hipEventRecord(c->ev0, s));
-    const uint64_t chunk = 1ull << 30;
-    for (uint64_t first64 = 0; first64 < total; first64 += chunk) {
-        unsigned first = (unsigned)first64;
-        unsigned cnt = (unsigned)((total - first64) < chunk ? (total - first64) : chunk);
-        unsigned tiles = (cnt + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    // launches cover whole planes (an even number of them), < 2^30 points each
+    const uint64_t plane = n1 * n1;
+    uint64_t planes_per = (1ull << 30) / plane;
+    planes_per = planes_per < 2 ? 1 : (planes_per & ~1ull);
+    const bool pairs = c->variant == 3 && d_nrm != nullptr && !getenv("DCSG_NO_PLANE_PAIRS");
+    hipFunction_t fn = pairs ? c->k->sweep_sp2 : c->k->sweep[c->variant];
+    for (uint64_t p0 = 0; p0 < (uint64_t)(z1 - z0); p0 += planes_per) {
+        uint64_t np = (uint64_t)(z1 - z0) - p0 < planes_per ? (uint64_t)(z1 - z0) - p0 : planes_per;
+        unsigned first = (unsigned)(p0 * plane);
+        unsigned cnt = (unsigned)(np * plane);
+        unsigned work = pairs ? (unsigned)(((np + 1) / 2) * plane) : cnt;
+        unsigned tiles = (work + DCSG_BLOCK - 1) / DCSG_BLOCK;
         void* args[] = {(void*)&blob, &nv, &L, &z0, &first, &cnt, (void*)&d_sdf, (void*)&d_nrm};
-        int r = launch(c, c->k->sweep[c->variant], sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), s, args);
+        int r = launch(c, fn, sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), s, args);
         if (r) return r;
     }
     if (time_it) {

@@ -29,7 +29,6 @@ float3 shader_bank(float3 gv, float3 lv, float3 n, unsigned char material_id);
 /* Correctly rounded sqrtf: same sequence as dcsg_sqrt in kernels.hip (fast path for waves whose inputs are
  * all >= 2^-96, the compiler's full IEEE expansion otherwise). */
 float dcsg_sqrt_ieee(float x){
-    if (__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f)) != 0ul) return __builtin_sqrtf(x);
     float r = __builtin_amdgcn_sqrtf(x);
     float rm = as_float(as_uint(r) - 1u);
     float rp = as_float(as_uint(r) + 1u);
@@ -37,6 +36,7 @@ float dcsg_sqrt_ieee(float x){
     float ep = __builtin_fmaf(-rp, r, x);
     r = 0.0f >= em ? rm : r;
     r = 0.0f < ep ? rp : r;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f)) != 0ul, 0)) r = __builtin_sqrtf(x);
     return r;
 }
 float  DCSG_OVL sqrt(float x){ return dcsg_sqrt_ieee(x); }

@@ -29,13 +29,16 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, std::str
         snprintf(line, sizeof(line), fmt, a...);
         out += line;
     };
-    if (N == 7)
+    static const char* hexdigit = "0123456789abcdef";
+    if (N == 14)
+        out += "float16 dcsg_spec_eval14(float16 px, float16 py, float16 pz){\n";
+    else if (N == 7)
         out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){\n";
     else
         out += "float dcsg_spec_eval1(float x, float y, float z){\n";
-    auto X = [&](int k) { return N == 7 ? "px.s" + std::to_string(k) : std::string("x"); };
-    auto Y = [&](int k) { return N == 7 ? "py.s" + std::to_string(k) : std::string("y"); };
-    auto Z = [&](int k) { return N == 7 ? "pz.s" + std::to_string(k) : std::string("z"); };
+    auto X = [&](int k) { return N > 1 ? std::string("px.s") + hexdigit[k] : std::string("x"); };
+    auto Y = [&](int k) { return N > 1 ? std::string("py.s") + hexdigit[k] : std::string("y"); };
+    auto Z = [&](int k) { return N > 1 ? std::string("pz.s") + hexdigit[k] : std::string("z"); };
     for (int k = 0; k < N; k++) P("  float o%d = (float)MAX_DISTANCE;\n", k);
     for (int d = 0; d < (s.stack_depth > 0 ? s.stack_depth : 1); d++)
         for (int k = 0; k < N; k++) P("  float s%d_%d = 0.0f;\n", d, k);
@@ -84,7 +87,9 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, std::str
             for (int k = 0; k < N; k++) P("  o%d = s%d_%d;\n", k, depth - 1, k);
         }
     }
-    if (N == 7)
+    if (N == 14)
+        out += "  return (float16)(o0, o1, o2, o3, o4, o5, o6, o7, o8, o9, o10, o11, o12, o13, 0.0f, 0.0f);\n}\n";
+    else if (N == 7)
         out += "  return (float8)(o0, o1, o2, o3, o4, o5, o6, 0.0f);\n}\n";
     else
         out += "  return o0;\n}\n";
@@ -97,10 +102,12 @@ std::string specialised_source(const Scene& s, bool null_brush_const, bool enabl
 {
     std::string out = "\n/* ---- generated by csrc/specialise.cpp ---- */\n";
     if (!enable || s.n_stack_prog == 0) {
+        out += "float16 dcsg_spec_eval14(float16 px, float16 py, float16 pz){ return (float16)(0.0f); }\n";
         out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){ return (float8)(0.0f); }\n";
         out += "float dcsg_spec_eval1(float x, float y, float z){ return 0.0f; }\n";
         return out;
     }
+    emit_function(s, null_brush_const, 14, out);
     emit_function(s, null_brush_const, 7, out);
     emit_function(s, null_brush_const, 1, out);
     return out;
