@@ -79,8 +79,11 @@ class Evaluator:
         """Load the files a design run leaves in its working directory."""
         rd = lambda n: open(os.path.join(scene_dir, n)).read()
         scl = rd("scene.cl") if use_scene_cl and os.path.exists(os.path.join(scene_dir, "scene.cl")) else None
-        adp = os.path.join(scene_dir, "arbitrary_data.hex")
-        ad = read_arbitrary_data(adp) if os.path.exists(adp) else None
+        ad = None
+        for name in ("arbitrary_data.hex", "arbitrary_data.prefix.hex"):  # the latter: fixture with the zero tail cut
+            if os.path.exists(os.path.join(scene_dir, name)):
+                ad = read_arbitrary_data(os.path.join(scene_dir, name))
+                break
         return self.build(rd("scene.txt"), rd("buildprocedure.txt"), scl, ad)
 
     def scene_info(self):

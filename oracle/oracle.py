@@ -147,7 +147,7 @@ class Scene:
         scl = os.path.join(d, "scene.cl")
         return cls(open(os.path.join(d, "scene.txt")).read(),
                    open(os.path.join(d, "buildprocedure.txt")).read(),
-                   scl if (use_scene_cl and os.path.exists(scl)) else None)
+                   scl if (use_scene_cl and os.path.exists(scl)) else None, read_arbitrary_data(d))
 
     def __del__(self):
         try:
@@ -206,6 +206,18 @@ class Scene:
         tris = np.ascontiguousarray(tris, dtype=np.float32).copy()
         lib().oracle_gradient_descent(self._h, steps, _ptr(tris), tris.shape[0], threads)
         return tris
+
+
+def read_arbitrary_data(d):
+    """arbitrary_data.hex (131072 LE f32) of a scene directory, or its stored non-zero prefix; None if absent."""
+    for name in ("arbitrary_data.hex", "arbitrary_data.prefix.hex"):
+        f = os.path.join(d, name)
+        if os.path.exists(f):
+            a = np.zeros(131072, dtype=np.float32)
+            v = np.fromfile(f, dtype="<f4")
+            a[:len(v)] = v
+            return a
+    return None
 
 
 def parse_export_config(text):

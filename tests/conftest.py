@@ -43,8 +43,13 @@ def scene_dir(name):
 
 def read_scene(name):
     d = scene_dir(name)
-    return {f: open(os.path.join(d, f)).read() for f in ("scene.txt", "buildprocedure.txt", "scene.cl",
-                                                          "exportConfig.txt")}
+    out = {f: open(os.path.join(d, f)).read() for f in ("scene.txt", "buildprocedure.txt", "scene.cl",
+                                                         "exportConfig.txt")}
+    ad = os.path.join(d, "arbitrary_data.prefix.hex")
+    if os.path.exists(ad):
+        import numpy as np
+        out["arbitrary_data"] = np.fromfile(ad, dtype="<f4")
+    return out
 
 
 def export_config_text(name, levels=None, gd=None):

@@ -37,6 +37,7 @@ DESIGNS = {
     "mixed_groups": os.path.join(OWN_DESIGNS, "mixed_groups.py"),
     "flat256": os.path.join(OWN_DESIGNS, "flat256.py"),
     "grouped256": os.path.join(OWN_DESIGNS, "grouped256.py"),
+    "ad_table": os.path.join(OWN_DESIGNS, "ad_table.py"),
 }
 FILES = ["scene.txt", "buildprocedure.txt", "scene.cl", "exportConfig.txt"]
 
@@ -55,6 +56,10 @@ def main():
             for f in FILES:
                 shutil.copyfile(os.path.join(scratch, f), os.path.join(out_dir, f))
             ad = open(os.path.join(scratch, "arbitrary_data.hex"), "rb").read()
+            nz = np.flatnonzero(np.frombuffer(ad, dtype="<f4"))
+            if len(nz):  # only the used prefix is kept; the rest of the 131072 floats is zero
+                with open(os.path.join(out_dir, "arbitrary_data.prefix.hex"), "wb") as fl:
+                    fl.write(ad[:4 * (int(nz[-1]) + 1)])
             n_obj = sum(1 for _ in open(os.path.join(out_dir, "scene.txt")))
             n_cmd = len(open(os.path.join(out_dir, "buildprocedure.txt")).read().split("\n"))
             manifest[name] = {

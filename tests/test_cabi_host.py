@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT, TABLE, read_scene, scene_dir
 
 HEADER = os.path.join(ROOT, "include", "dcsg.h")
-ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256"]
+ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table"]
 
 
 def declared_functions():
@@ -143,9 +143,17 @@ class object_values(dict):
 
     def __missing__(self, key):
         brush, obj = key
-        mini = self.oracle.Scene(self.scene["scene.txt"], "0 %d %d 0\n1 0 -1 -1" % (brush, obj), self.cl)
+        mini = _oracle_scene(self.oracle, self.scene["scene.txt"], "0 %d %d 0\n1 0 -1 -1" % (brush, obj), self.scene)
         self[key] = mini.eval_sdf(self.pts)
         return self[key]
+
+
+def _oracle_scene(oracle, scene_txt, bp, scene):
+    ad = None
+    if "arbitrary_data" in scene:
+        ad = np.zeros(131072, dtype=np.float32)
+        ad[:len(scene["arbitrary_data"])] = scene["arbitrary_data"]
+    return oracle.Scene(scene_txt, bp, os.path.join(scene["dir"], "scene.cl"), ad)
 
 
 def tmin(a, b):

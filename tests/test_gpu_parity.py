@@ -11,7 +11,7 @@ from conftest import export_config_text, read_scene, scene_dir
 
 pytestmark = pytest.mark.gpu
 
-ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256"]
+ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table"]
 STL_TOL = 1e-5  # north_star: ".stl diff within 1e-5"
 
 
@@ -25,7 +25,7 @@ def ev(built_lib):
 
 def load(ev, name):
     s = read_scene(name)
-    status, log = ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])
+    status, log = ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"], s.get("arbitrary_data"))
     assert status == 0, log
     return s
 
@@ -40,10 +40,11 @@ def sorted_tris(t):
     return b[np.lexsort(b.T[::-1])]
 
 
-EXPECTED_STACK_DEPTH = {"sphere": 1, "design1": 1, "design2": 1, "flat256": 1, "mixed_groups": 2, "grouped256": 2}
+EXPECTED_STACK_DEPTH = {"sphere": 1, "design1": 1, "design2": 1, "flat256": 1, "mixed_groups": 2, "grouped256": 2,
+                        "ad_table": 1}
 
 
-SPECIALISED = {"sphere", "design1", "design2", "mixed_groups"}  # <= 48 object evaluations
+SPECIALISED = {"sphere", "design1", "design2", "mixed_groups", "ad_table"}  # <= 48 object evaluations
 
 
 @pytest.mark.parametrize("interpreter", ["auto", "stack", "generic"])
@@ -89,7 +90,7 @@ def test_builtin_bank_equals_jit_bank(ev, oracle):
     assert np.array_equal(bits(a), bits(b))
 
 
-@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups"])
+@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table"])
 def test_lattice_sweep_bit_exact(ev, oracle, name):
     load(ev, name)
     osc = oracle.Scene.from_dir(scene_dir(name))
@@ -130,7 +131,7 @@ GOLD_TRIS_128 = {  # levels 4/6/7, per-level triangle counts
 }
 
 
-@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups"])
+@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups", "ad_table"])
 @pytest.mark.parametrize("dense_normals", [False, True])
 def test_mesher_and_projection_bit_exact(ev, oracle, lookup_table, name, dense_normals, tmp_path):
     load(ev, name)
@@ -286,3 +287,19 @@ def test_sqrt_all_float_inputs(ev, module):
         assert np.array_equal(np.isnan(got), nan), hex(c)
         assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32)), hex(c)
         del bits
+
+
+def test_set_arbitrary_data_after_build(ev, oracle):
+    """Evaluator::setArbitraryData (Evaluator.cpp:213-225) on a loaded scene: the brushes see the new table."""
+    s = load(ev, "ad_table")
+    rng = np.random.default_rng(8)
+    pts = rng.uniform(-3.0, 3.0, (20_000, 3)).astype(np.float32)
+    a = ev.eval_sdf_at_points(pts)
+    table = np.zeros(131072, dtype=np.float32)
+    table[:len(s["arbitrary_data"])] = s["arbitrary_data"]
+    table[36:48] *= np.float32(1.5)  # AD_BLOB_RADII
+    ev.setArbitraryData(table)
+    b = ev.eval_sdf_at_points(pts)
+    osc = oracle.Scene(s["scene.txt"], s["buildprocedure.txt"], scene_dir("ad_table") + "/scene.cl", table)
+    assert not np.array_equal(a, b)
+    assert np.array_equal(bits(b), bits(osc.eval_sdf(pts)))
