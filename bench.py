@@ -62,18 +62,27 @@ def cpu_baseline(scene_dir, center, diameter, res, budget_s=15.0):
     t0 = time.perf_counter()
     osc.eval_lattice(center, diameter, res, z, z + 2, threads=cores)
     t1 = (time.perf_counter() - t0) / 2
-    planes = max(1, min(n1 - z, int(budget_s / max(t1, 1e-4))))
+    want = max(1, int(budget_s / max(t1, 1e-5)))  # planes worth ~budget_s of CPU time
+    chunk = min(64, n1)                            # planes per call: bounds the result buffers (64*n1^2*16 B)
+    pts, planes, z = 0, 0, 0
     t0 = time.perf_counter()
-    osc.eval_lattice(center, diameter, res, z, z + planes, threads=cores)
+    while planes < want:
+        k = min(chunk, want - planes, n1 - z)
+        osc.eval_lattice(center, diameter, res, z, z + k, threads=cores)
+        planes += k
+        pts += k * n1 * n1
+        z = (z + k) % n1                           # wraps: several passes over the lattice if it is cheap
     dt = time.perf_counter() - t0
-    pts = planes * n1 * n1
     # voxels per lattice point, so that the unit matches `value`
     mvox = pts * (res ** 3 / n1 ** 3) / dt / 1e6
     return {"value": round(mvox, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
-            "sample": "oracle fused SDF+normal on %d of %d lattice planes (%d points, %.1f s)" % (planes, n1, pts, dt)}
+            "sample": "oracle fused SDF+normal on %d lattice planes of %d^2 points (%.2f passes over the %d^3 lattice, "
+                      "%d points, %.1f s)" % (planes, n1, planes / n1, n1, pts, dt)}
 
 
-KERNEL_VARIANT = {0: "dcsg_sweep", 1: "dcsg_sweep_s4", 2: "dcsg_sweep_s8", 3: "dcsg_sweep_sp"}
+# kernel that a fused SDF+normal sweep launches, by interpreter variant (dcsg_api.cpp: sweep_device)
+KERNEL_VARIANT = {0: "dcsg_sweep", 1: "dcsg_sweep_s4", 2: "dcsg_sweep_s8",
+                  3: "dcsg_sweep_sp" if os.environ.get("DCSG_NO_PLANE_PAIRS") else "dcsg_sweep_sp2"}
 
 
 def profiled_traffic(kernel, workload):
@@ -101,6 +110,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sphere512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-halo", action="store_true", help="after the timed loop, check the received halo plane")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default, what the driver runs); gloo = rehearsal of the N>1 logic on "
+                         "a box with fewer GPUs than ranks: halo planes are staged through host memory")
     args = ap.parse_args()
 
     import torch
@@ -113,10 +126,15 @@ def main():
     if world != args.gpus:
         sys.exit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                  % (args.gpus, world, args.gpus))
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     scene, grid_level, center, diameter = WORKLOADS[args.workload]
     scene_dir = os.path.join(ROOT, "tests", "golden", "scenes", scene)
@@ -137,23 +155,54 @@ def main():
     nrm = torch.empty(planes * plane * 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
 
+    halo_sdf, halo_nrm = sdf[(hi - lo) * plane:], nrm[(hi - lo) * plane * 3:]  # plane hi (neighbour's first)
+
+    # Pre-bound C call: the per-step host work is two launches and one grouped RCCL exchange.
+    import ctypes as C
+    from designcsg_amd import _lib
+    L, h = _lib.lib(), ev._h
+    c3 = (C.c_float * 3)(*center)
+    d3 = (C.c_float * 3)(diameter, diameter, diameter)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def sweep(z_a, z_b):
+        off = z_a - lo
+        rc = L.dcsg_sweep_lattice_device(h, c3, d3, res, z_a, z_b, C.c_void_p(sdf.data_ptr() + off * plane * 4),
+                                         C.c_void_p(nrm.data_ptr() + off * plane * 12), sp)
+        if rc:
+            _lib.check(h, rc)
+
+    send_first = world > 1 and rank > 0
+    recv_halo = world > 1 and rank < world - 1
+    if args.backend == "nccl" and world > 1:
+        ops = []
+        if send_first:
+            ops += [dist.P2POp(dist.isend, sdf[:plane], rank - 1), dist.P2POp(dist.isend, nrm[:3 * plane], rank - 1)]
+        if recv_halo:
+            ops += [dist.P2POp(dist.irecv, halo_sdf, rank + 1), dist.P2POp(dist.irecv, halo_nrm, rank + 1)]
+
     def step():
-        # own planes; the first one is what the lower neighbour needs, so it goes first
-        if world > 1 and rank > 0:
-            ev.sweep_lattice_device(center, diameter, res, lo, lo + 1, sdf.data_ptr(), nrm.data_ptr(),
-                                    stream.cuda_stream)
-            reqs = [dist.isend(sdf[:plane], rank - 1), dist.isend(nrm[:3 * plane], rank - 1)]
+        # own planes; the first one is what the lower neighbour needs, so it goes first and its transfer
+        # (one grouped send/recv with both Z neighbours) overlaps the sweep of the rest of the slab
+        first, staged, reqs = lo, None, []
+        if send_first:
+            sweep(lo, lo + 1)
             first = lo + 1
-        else:
-            reqs, first = [], lo
-        if world > 1 and rank < world - 1:
-            reqs += [dist.irecv(sdf[(hi - lo) * plane:], rank + 1), dist.irecv(nrm[(hi - lo) * plane * 3:], rank + 1)]
-        off = first - lo
-        ev.sweep_lattice_device(center, diameter, res, first, own_hi,
-                                sdf.data_ptr() + off * plane * 4, nrm.data_ptr() + off * plane * 12,
-                                stream.cuda_stream)
+        if world > 1:
+            if args.backend == "nccl":
+                reqs = dist.batch_isend_irecv(ops) if ops else []
+            else:
+                if send_first:
+                    reqs += [dist.isend(sdf[:plane].cpu(), rank - 1), dist.isend(nrm[:3 * plane].cpu(), rank - 1)]
+                if recv_halo:
+                    staged = (torch.empty(plane, dtype=torch.float32), torch.empty(3 * plane, dtype=torch.float32))
+                    reqs += [dist.irecv(staged[0], rank + 1), dist.irecv(staged[1], rank + 1)]
+        sweep(first, own_hi)
         for r in reqs:
             r.wait()
+        if staged is not None:
+            halo_sdf.copy_(staged[0])
+            halo_nrm.copy_(staged[1])
 
     def barrier():
         if world > 1:
@@ -172,8 +221,19 @@ def main():
         k_ev[i][1].record(stream)
     barrier()
     dt = time.perf_counter() - t0
+    if args.verify_halo and world > 1 and rank < world - 1:
+        # the plane received from the upper neighbour must equal what this rank computes for it
+        chk = torch.empty(plane, dtype=torch.float32, device="cuda")
+        chn = torch.empty(3 * plane, dtype=torch.float32, device="cuda")
+        ev.sweep_lattice_device(center, diameter, res, hi, hi + 1, chk.data_ptr(), chn.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        if not (torch.equal(chk.view(torch.int32), halo_sdf.view(torch.int32))
+                and torch.equal(chn.view(torch.int32), halo_nrm.view(torch.int32))):
+            sys.exit("rank %d: halo plane %d differs from the local evaluation" % (rank, hi))
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
+        if args.backend == "gloo":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
