@@ -71,7 +71,7 @@ def build(verbose=False, prebuild_scenes=True):
     if _newer(LIB, host_deps):
         _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
               "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"), "-I" + OUT, "-I" + CSRC]
-             + host_src + ["-o", LIB, "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-ldl",
+             + host_src + ["-o", LIB, "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-ldl", "-lpthread",
                            "-Wl,-rpath," + os.path.join(ROCM, "lib")])
     if prebuild_scenes:
         prebuild_jit_cache(verbose)

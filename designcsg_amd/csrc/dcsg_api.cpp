@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dcsg.h"
@@ -62,6 +63,8 @@ struct dcsg_ctx {
     DevBuf d_blob, d_ad, d_tri_table, d_pts, d_out, d_nodes[2], d_info, d_block_sums, d_small, d_tris, d_lat_sdf,
         d_lat_nrm;
     uint64_t n_tris = 0;
+    void* h_pinned = nullptr;  // host staging for triangle downloads
+    size_t h_pinned_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_sweep_time = false;
     std::string err;
@@ -370,6 +373,7 @@ void dcsg_destroy(dcsg_ctx* c)
                       &c->d_nodes[1], &c->d_info,    &c->d_block_sums, &c->d_small, &c->d_tris, &c->d_lat_sdf,
                       &c->d_lat_nrm};
     for (auto* b : bufs) release(*b);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->scene_mod) hipModuleUnload(c->scene_mod);
     if (c->builtin_mod) hipModuleUnload(c->builtin_mod);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -765,26 +769,57 @@ int dcsg_copy_triangles_device(dcsg_ctx* c, float* d_out, uint64_t max_triangles
     return 0;
 }
 
+// File images are formatted by a few host threads straight into one malloc'd buffer (no zero-fill pass) and
+// written with a single write; dcsg_export formats and writes the two files concurrently.
+}  // extern "C"
+
+namespace {
+
+template <class F>
+void parallel_chunks(uint64_t n, F f)
+{
+    unsigned nt = n > (1u << 16) ? 4u : 1u;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
+    f(0, n / nt);
+    for (auto& x : th) x.join();
+}
+
+int write_whole(const char* path, const unsigned char* buf, size_t bytes)
+{
+    FILE* f = fopen(path, "wb");
+    if (!f) return DCSG_ERR_IO;
+    size_t w = fwrite(buf, 1, bytes, f);
+    return (fclose(f) == 0 && w == bytes) ? 0 : DCSG_ERR_IO;
+}
+
+}  // namespace
+
+extern "C" {
+
 // writeTrianglesToSTL, utils.hpp:41-103: 80 zero bytes, u32 count, per triangle a zero normal, then
 // A, B, C each written as (x, z, y), then u16 0.  Little-endian host assumed (x86-64).
 int dcsg_write_stl(const char* path, const float* tris, uint64_t n)
 {
     if (!path || (n && !tris)) return DCSG_ERR_INVALID;
     size_t bytes = 84 + (size_t)n * 50;
-    std::vector<unsigned char> buf(bytes, 0);
+    unsigned char* buf = (unsigned char*)malloc(bytes);
+    if (!buf) return DCSG_ERR_IO;
+    memset(buf, 0, 84);
     uint32_t n32 = (uint32_t)n;
-    memcpy(&buf[80], &n32, 4);
-    unsigned char* o = &buf[84];
-    for (uint64_t t = 0; t < n; t++, o += 50) {
-        const float* v = tris + t * 9;
-        float rec[9] = {v[0], v[2], v[1], v[3], v[5], v[4], v[6], v[8], v[7]};
-        memcpy(o + 12, rec, 36);
-    }
-    FILE* f = fopen(path, "wb");
-    if (!f) return DCSG_ERR_IO;
-    size_t w = fwrite(buf.data(), 1, bytes, f);
-    int ok = fclose(f) == 0 && w == bytes;
-    return ok ? 0 : DCSG_ERR_IO;
+    memcpy(buf + 80, &n32, 4);
+    parallel_chunks(n, [=](uint64_t t0, uint64_t t1) {
+        unsigned char* o = buf + 84 + t0 * 50;
+        for (uint64_t t = t0; t < t1; t++, o += 50) {
+            const float* v = tris + t * 9;
+            float rec[12] = {0.0f, 0.0f, 0.0f, v[0], v[2], v[1], v[3], v[5], v[4], v[6], v[8], v[7]};
+            memcpy(o, rec, 48);
+            o[48] = o[49] = 0;
+        }
+    });
+    int rc = write_whole(path, buf, bytes);
+    free(buf);
+    return rc;
 }
 
 // writeTrianglesToPLY, utils.hpp:106-154 via happly.h:1998-2039 (header), 1538-1570 (double x,y,z),
@@ -800,25 +835,27 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
                       "element face %llu\nproperty list uchar uint vertex_indices\nend_header\n",
                       (unsigned long long)(n * 3), (unsigned long long)n);
     size_t bytes = (size_t)hl + (size_t)n * (72 + 13);
-    std::vector<unsigned char> buf(bytes);
-    memcpy(buf.data(), header, hl);
-    double* d = (double*)(buf.data() + hl);  // unaligned stores are fine on x86-64; use memcpy to be strict
-    unsigned char* o = buf.data() + hl;
-    for (uint64_t i = 0; i < n * 9; i++, o += 8) {
-        double v = (double)tris[i];
-        memcpy(o, &v, 8);
-    }
-    (void)d;
-    for (uint64_t t = 0; t < n; t++, o += 13) {
-        o[0] = 3;
-        uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
-        memcpy(o + 1, idx, 12);
-    }
-    FILE* f = fopen(path, "wb");
-    if (!f) return DCSG_ERR_IO;
-    size_t w = fwrite(buf.data(), 1, bytes, f);
-    int ok = fclose(f) == 0 && w == bytes;
-    return ok ? 0 : DCSG_ERR_IO;
+    unsigned char* buf = (unsigned char*)malloc(bytes);
+    if (!buf) return DCSG_ERR_IO;
+    memcpy(buf, header, hl);
+    unsigned char* verts = buf + hl;
+    unsigned char* faces = verts + (size_t)n * 72;
+    parallel_chunks(n, [=](uint64_t t0, uint64_t t1) {
+        unsigned char* o = verts + t0 * 72;
+        for (uint64_t i = t0 * 9; i < t1 * 9; i++, o += 8) {
+            double v = (double)tris[i];
+            memcpy(o, &v, 8);
+        }
+        unsigned char* q = faces + t0 * 13;
+        for (uint64_t t = t0; t < t1; t++, q += 13) {
+            q[0] = 3;
+            uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
+            memcpy(q + 1, idx, 12);
+        }
+    });
+    int rc = write_whole(path, buf, bytes);
+    free(buf);
+    return rc;
 }
 
 int dcsg_debug_sqrt_device(dcsg_ctx* c, const float* d_in, size_t n, float* d_out, void* stream)
@@ -946,19 +983,38 @@ int dcsg_export(dcsg_ctx* c, const char* cfg_txt, const char* stl_path, const ch
 
     if (stl_path || ply_path) {
         t0 = now_s();
-        std::vector<float> host((size_t)n_tris * 9 + 1);
-        if ((r = dcsg_download_triangles(c, host.data(), n_tris))) return r;
+        // pinned staging buffer (kept across exports): the download runs at PCIe rate instead of pageable rate
+        size_t need = (size_t)n_tris * 9 * sizeof(float) + 64;
+        if (need > c->h_pinned_cap) {
+            if (c->h_pinned) hipHostFree(c->h_pinned);
+            c->h_pinned = nullptr;
+            c->h_pinned_cap = 0;
+            HIPCHK(c, hipHostMalloc(&c->h_pinned, need + need / 4, hipHostMallocDefault));
+            c->h_pinned_cap = need + need / 4;
+        }
+        float* host = (float*)c->h_pinned;
+        if ((r = dcsg_download_triangles(c, host, n_tris))) return r;
         st.t_download = now_s() - t0;
+        t0 = now_s();
+        int rc_stl = 0, rc_ply = 0;
+        double dt_stl = 0, dt_ply = 0;
+        std::thread ply_thread;
+        if (ply_path)
+            ply_thread = std::thread([&] {
+                double a = now_s();
+                rc_ply = dcsg_write_ply(ply_path, host, n_tris);
+                dt_ply = now_s() - a;
+            });
         if (stl_path) {
-            t0 = now_s();
-            if ((r = dcsg_write_stl(stl_path, host.data(), n_tris))) return fail(c, r, "cannot write STL");
-            st.t_write_stl = now_s() - t0;
+            double a = now_s();
+            rc_stl = dcsg_write_stl(stl_path, host, n_tris);
+            dt_stl = now_s() - a;
         }
-        if (ply_path) {
-            t0 = now_s();
-            if ((r = dcsg_write_ply(ply_path, host.data(), n_tris))) return fail(c, r, "cannot write PLY");
-            st.t_write_ply = now_s() - t0;
-        }
+        if (ply_thread.joinable()) ply_thread.join();
+        st.t_write_stl = dt_stl;  // the two writers overlap: their sum exceeds the wall time of this stage
+        st.t_write_ply = dt_ply;
+        if (rc_stl) return fail(c, rc_stl, "cannot write STL");
+        if (rc_ply) return fail(c, rc_ply, "cannot write PLY");
     }
     st.t_total = now_s() - t_start;
     if (stats) *stats = st;
