@@ -82,7 +82,7 @@ def cpu_baseline(scene_dir, center, diameter, res, budget_s=15.0):
 
 # kernel that a fused SDF+normal sweep launches, by interpreter variant (dcsg_api.cpp: sweep_device)
 KERNEL_VARIANT = {0: "dcsg_sweep", 1: "dcsg_sweep_s4", 2: "dcsg_sweep_s8",
-                  3: "dcsg_sweep_sp" if os.environ.get("DCSG_NO_PLANE_PAIRS") else "dcsg_sweep_sp2"}
+                  3: "dcsg_sweep_sp" if os.environ.get("DCSG_NO_PLANE_PAIRS") else "dcsg_sweep_sp2", 4: "dcsg_sweep_c4"}
 
 
 def profiled_traffic(kernel, workload):

@@ -31,9 +31,10 @@ struct DevBuf {
 
 // Variants of the evaluation kernels (kernels.hip): [0] generic interpreter (register program, stack in
 // LDS, any program), [1] / [2] stack-program interpreter with a register-resident stack of depth <= 4 / <= 8,
-// [3] per-scene specialised code (scene modules only).
+// [3] per-scene specialised code (scene modules only), [4] stack interpreter with tile culling (stand-alone
+// module only: needs the known Lipschitz bounds of the built-in brushes; eval_points[4] aliases [1]).
 struct Kernels {
-    hipFunction_t sweep[4] = {}, eval_points[4] = {}, bbox[4] = {}, project[4] = {};
+    hipFunction_t sweep[5] = {}, eval_points[5] = {}, bbox[5] = {}, project[5] = {};
     hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr;
     hipFunction_t sweep_sp2 = nullptr;  // specialised sweep, two planes per thread (scene modules only)
 };
@@ -135,6 +136,12 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
     } tab[] = {{"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan}, {"dcsg_mesh_emit", &k.emit},
                {"dcsg_test_sqrt", &k.test_sqrt}};
     for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
+    if (!scene_module) {
+        HIPCHK(c, hipModuleGetFunction(&k.sweep[4], mod, "dcsg_sweep_c4"));
+        HIPCHK(c, hipModuleGetFunction(&k.bbox[4], mod, "dcsg_bbox_c4"));
+        HIPCHK(c, hipModuleGetFunction(&k.project[4], mod, "dcsg_project_c4"));
+        k.eval_points[4] = k.eval_points[1];  // arbitrary points have no spatial coherence to exploit
+    }
     if (scene_module) {
         HIPCHK(c, hipModuleGetFunction(&k.set_ad, mod, "dcsg_set_arbitrary_data"));
         HIPCHK(c, hipModuleGetFunction(&k.sweep_sp2, mod, "dcsg_sweep_sp2"));
@@ -454,9 +461,23 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     c->scene = std::move(s);
     const int depth = c->scene.n_stack_prog ? c->scene.stack_depth : 1000;
     c->variant = c->specialised ? 3 : (depth <= 4 ? 1 : (depth <= 8 ? 2 : 0));
+    // Tile culling: stand-alone module (built-in brushes), flat program (depth 1) with enough objects to pay off.
+    {
+        int n_evals = 0;
+        bool flat = c->scene.n_stack_prog > 0 && c->scene.stack_depth == 1;
+        for (int k = 0; k < c->scene.n_stack_prog; k++) {
+            int op = c->scene.stack_prog[4 * k];
+            n_evals += op <= 35 ? 1 : 0;
+            if (op >= 36 && op <= 38) flat = false;
+        }
+        const char* env_cull = getenv("DCSG_CULL");
+        int min_objects = env_cull ? atoi(env_cull) : 16;  // 0 disables
+        if (!c->jit && flat && min_objects > 0 && n_evals >= min_objects) c->variant = 4;
+    }
     if (const char* force = getenv("DCSG_FORCE_VARIANT")) {  // A/B testing only; never exceeds what the program fits
         int f = atoi(force);
         if (f == 0 || (f == 1 && depth <= 4) || (f == 2 && depth <= 8)) c->variant = f;
+        if (f == 4 && c->variant != 4) c->variant = c->variant;  // culling is only ever chosen by the rule above
     }
     c->scene_loaded = true;
     c->n_tris = 0;

@@ -133,6 +133,7 @@ struct SceneLds {
     float* stack;  // generic interpreter's LDS stack, already offset by threadIdx.x
     int n_steps;
     int n_stack_steps;
+    int n_regs;
     int flags;
 };
 
@@ -144,6 +145,7 @@ __device__ __forceinline__ SceneLds dcsg_stage_scene(const uint4* __restrict__ b
     int n_steps = __builtin_amdgcn_readfirstlane((int)dcsg_lds[0].x);
     s.n_steps = n_steps;
     s.flags = __builtin_amdgcn_readfirstlane((int)dcsg_lds[0].w);
+    s.n_regs = __builtin_amdgcn_readfirstlane((int)dcsg_lds[0].z);
     int n_stack = __builtin_amdgcn_readfirstlane((int)dcsg_lds[1].x);
     s.n_stack_steps = n_stack;
     s.steps = reinterpret_cast<const int4*>(dcsg_lds + 2);
@@ -331,9 +333,12 @@ __device__ __forceinline__ void dcsg_bank_n(const float (&A)[N], const float (&B
 #define SOP_POP_NEGMAX 38
 #define SOP_EXPORT_TOP 39
 
+// `list` (LDS, wave-uniform contents) optionally restricts the pass to a subset of the steps, in program
+// order: the active-step list of the tile culling below.
 template <int D, int N>
 __device__ __forceinline__ void dcsg_interp(const SceneLds& s, const float (&px)[N], const float (&py)[N],
-                                            const float (&pz)[N], float (&out)[N])
+                                            const float (&pz)[N], float (&out)[N],
+                                            const unsigned short* list = nullptr, int n_list = 0)
 {
     float stk[D][N];  // stk[0] = top of stack
 #pragma unroll
@@ -342,7 +347,9 @@ __device__ __forceinline__ void dcsg_interp(const SceneLds& s, const float (&px)
         for (int k = 0; k < N; k++) stk[i][k] = 0.0f;
 #pragma unroll
     for (int k = 0; k < N; k++) out[k] = (float)K2_MAX_DISTANCE;
-    for (int c = 0; c < s.n_stack_steps; c++) {
+    const int n_run = list ? n_list : s.n_stack_steps;
+    for (int k_run = 0; k_run < n_run; k_run++) {
+        const int c = list ? __builtin_amdgcn_readfirstlane((int)list[k_run]) : k_run;
         int4 st = s.stack_steps[c];
         int op = __builtin_amdgcn_readfirstlane(st.x);
         int left = __builtin_amdgcn_readfirstlane(st.y);
@@ -425,11 +432,12 @@ __device__ __forceinline__ bool dcsg_is_neg_zero(float v) { return __float_as_ui
 // the unperturbed coordinates as shared values (see dcsg_interp).
 template <int K>
 __device__ __forceinline__ void dcsg_stencil(const SceneLds& s, float x, float y, float z, bool want_sdf,
-                                             bool want_normal, float& sdf, float& nx, float& ny, float& nz)
+                                             bool want_normal, float& sdf, float& nx, float& ny, float& nz,
+                                             const unsigned short* list = nullptr, int n_list = 0)
 {
     if (!want_normal) {
         float p0[1] = {x}, p1[1] = {y}, p2[1] = {z}, o[1];
-        dcsg_interp<K, 1>(s, p0, p1, p2, o);
+        dcsg_interp<K, 1>(s, p0, p1, p2, o, list, n_list);
         sdf = o[0];
         return;
     }
@@ -449,10 +457,112 @@ __device__ __forceinline__ void dcsg_stencil(const SceneLds& s, float x, float y
     float py[7] = {y, y, y, yp, ym, y, y};
     float pz[7] = {z, z, z, z, z, zp, zm};
     float o[7];
-    dcsg_interp<K, 7>(s, px, py, pz, o);
+    dcsg_interp<K, 7>(s, px, py, pz, o, list, n_list);
     sdf = o[0];
     dcsg_finish_normal(o[1] - o[2], o[3] - o[4], o[5] - o[6], nx, ny, nz);
 }
+
+#ifndef DCSG_EXTERN_BANK
+// ---------------------------------------------------------------------------
+// Tile culling for many-object scenes (flat programs over the built-in brushes).
+//
+// A wave evaluates 64 points that sit close together (a run of the lattice, a cluster of mesh vertices).
+// Before interpreting the program for them it bounds every object's value over the tile,
+//     s_i(p) in [c_i - m_i, c_i + m_i],  c_i = s_i(tile centre),  m_i = L_i * R + float margin,
+// (L_i = Lipschitz constant of brush_i o transform_i: the built-in brushes have gradient norm <= 1, so
+// L_i <= ||[right;up;forward]||_F, precomputed by the host; R = radius of the tile including the normal
+// stencil), and pushes an interval [lo, hi] that contains the accumulator at every point of the tile through
+// the program.  A step "acc = T_min(acc, s_i)" cannot change acc anywhere in the tile when c_i - m_i > hi
+// (T_min(a,b) = a<b?a:b returns a whenever a < b); likewise T_max / T_max(-s).  Only the steps that may matter
+// are written to an LDS list and interpreted -- with exactly the same arithmetic, so results stay
+// bit-identical (tests/test_gpu_parity.py, tests/test_gpu_fullsize.py compare with the oracle).
+// 64 objects are bounded per pass (one per lane); the interval walk is a wave-uniform loop.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min_f(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, DCSG_WAVE));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, DCSG_WAVE));
+    return v;
+}
+
+// Builds the wave's active-step list for the tile that contains the valid lanes' points (x,y,z); `pad` is
+// added to every half extent (the stencil's epsilon).  Returns the number of steps kept (wave-uniform).
+__device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool valid, float x, float y, float z, float pad,
+                                                      unsigned short* list)
+{
+    const int lane = threadIdx.x & (DCSG_WAVE - 1);
+    const float inf = __builtin_inff();
+    float x0 = wave_min_f(valid ? x : inf), x1 = wave_max_f(valid ? x : -inf);
+    float y0 = wave_min_f(valid ? y : inf), y1 = wave_max_f(valid ? y : -inf);
+    float z0 = wave_min_f(valid ? z : inf), z1 = wave_max_f(valid ? z : -inf);
+    float cx = 0.5f * (x0 + x1), cy = 0.5f * (y0 + y1), cz = 0.5f * (z0 + z1);
+    float hx = 0.5f * (x1 - x0) + pad, hy = 0.5f * (y1 - y0) + pad, hz = 0.5f * (z1 - z0) + pad;
+    float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
+    const int n = s.n_stack_steps;
+    float lo = 0.0f, hi = 0.0f;
+    int n_active = 0;
+    for (int base = 0; base < n; base += DCSG_WAVE) {
+        int c = base + lane;
+        int op = -1;
+        float lb = 0.0f, ub = 0.0f;
+        if (c < n) {
+            int4 st = s.stack_steps[c];
+            op = st.x;
+            if (op <= SOP_ACC_NEGMAX) {
+                int shape = st.y & 0xff;
+                float val, L;
+                if (shape == 0 && (s.flags & 1)) {
+                    val = (float)K2_MAX_DISTANCE;
+                    L = 0.0f;
+                } else {
+                    float4 q1 = s.obj[4 * st.z + 1];
+                    val = dcsg_import(s, shape, st.z, cx, cy, cz);
+                    L = q1.w;
+                }
+                float m = L * R * 1.0001f + 1e-3f + 1e-5f * __builtin_fabsf(val);
+                lb = val - m;
+                ub = val + m;
+            }
+        }
+        int cnt = n - base < DCSG_WAVE ? n - base : DCSG_WAVE;
+        for (int l = 0; l < cnt; l++) {
+            int o = __builtin_amdgcn_readlane(op, l);
+            float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb), l));
+            float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ub), l));
+            bool keep = true;
+            if (o == SOP_PUSH) {
+                lo = b0;
+                hi = b1;
+            } else if (o == SOP_ACC_MIN) {
+                keep = !(b0 > hi);
+                lo = fminf(lo, b0);
+                hi = fminf(hi, b1);
+            } else if (o == SOP_ACC_MAX) {
+                keep = !(b1 < lo);
+                lo = fmaxf(lo, b0);
+                hi = fmaxf(hi, b1);
+            } else if (o == SOP_ACC_NEGMAX) {
+                keep = !(-b0 < lo);
+                lo = fmaxf(lo, -b1);
+                hi = fmaxf(hi, -b0);
+            }
+            if (keep) {
+                if (lane == 0) list[n_active] = (unsigned short)(base + l);
+                n_active++;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return n_active;
+}
+#define DCSG_HAVE_CULL 1
+#endif
 
 #ifdef DCSG_HAVE_SPEC
 // Out-of-line copy for waves that hold a -0.0 coordinate (exact "+ 0.0f" stencil, no shared values).
@@ -1145,6 +1255,128 @@ DCSG_PROJECT_KERNEL(dcsg_project_s4, 4)
 DCSG_PROJECT_KERNEL(dcsg_project_s8, 8)
 #ifdef DCSG_HAVE_SPEC
 DCSG_PROJECT_KERNEL(dcsg_project_sp, -1)
+#endif
+
+#ifdef DCSG_HAVE_CULL
+// ---------------------------------------------------------------------------
+// Culling variants of the evaluation kernels (built-in brush bank, flat programs; see dcsg_build_active_list).
+// The per-wave active-step lists live in LDS behind the generic interpreter's stack.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short* dcsg_wave_list(const SceneLds& s, int n_vec4)
+{
+    unsigned short* lists =
+        reinterpret_cast<unsigned short*>(reinterpret_cast<float*>(dcsg_lds + n_vec4) + s.n_regs * DCSG_BLOCK);
+    int cap = (s.n_stack_steps + 7) & ~7;
+    return lists + (threadIdx.x / DCSG_WAVE) * cap;
+}
+
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_sweep_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,
+              unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    unsigned short* list = dcsg_wave_list(s, n_vec4);
+    const unsigned int n1 = (unsigned int)L.res + 1u;
+    const unsigned int tiles = (n_points + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    const float pad = nrm_out ? (float)K2_NORMAL_EPSILON * 1.01f : 0.0f;
+    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        unsigned int local = tile * DCSG_BLOCK + threadIdx.x;
+        bool valid = local < n_points;
+        unsigned int idx = first + (valid ? local : 0u);
+        unsigned int t = dcsg_div_n1(L, idx);
+        unsigned int ix = idx - t * n1;
+        unsigned int iz = dcsg_div_n1(L, t);
+        unsigned int iy = t - iz * n1;
+        float x = dcsg_lattice_coord(L, 0, (int)ix);
+        float y = dcsg_lattice_coord(L, 1, (int)iy);
+        float z = dcsg_lattice_coord(L, 2, (int)iz + z0);
+        int n_list = dcsg_build_active_list(s, valid, x, y, z, pad, list);
+        float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+        dcsg_stencil<4>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz, list, n_list);
+        if (valid) {
+            if (sdf_out) sdf_out[idx] = sd;
+            if (nrm_out) {
+                float* o = nrm_out + (size_t)idx * 3;
+                o[0] = nx;
+                o[1] = ny;
+                o[2] = nz;
+            }
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, double bb_eps, int* __restrict__ result)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    unsigned short* list = dcsg_wave_list(s, n_vec4);
+    const unsigned int total = 256u * 256u * 256u;  // a multiple of the block size: every lane is valid
+    int mn[3] = {1 << 20, 1 << 20, 1 << 20};
+    int mx[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
+    unsigned int cnt = 0;
+    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < total; i += gridDim.x * DCSG_BLOCK) {
+        int iz = (int)(i & 255u) - 128;
+        int iy = (int)((i >> 8) & 255u) - 128;
+        int ix = (int)(i >> 16) - 128;
+        float x = half_neg + cd * (float)ix;
+        float y = half_neg + cd * (float)iy;
+        float z = half_neg + cd * (float)iz;
+        int n_list = dcsg_build_active_list(s, true, x, y, z, 0.0f, list);
+        float v, u0, u1, u2;
+        dcsg_stencil<4>(s, x, y, z, true, false, v, u0, u1, u2, list, n_list);
+        if ((double)v < bb_eps) {
+            cnt++;
+            mn[0] = ix < mn[0] ? ix : mn[0];
+            mx[0] = ix > mx[0] ? ix : mx[0];
+            mn[1] = iy < mn[1] ? iy : mn[1];
+            mx[1] = iy > mx[1] ? iy : mx[1];
+            mn[2] = iz < mn[2] ? iz : mn[2];
+            mx[2] = iz > mx[2] ? iz : mx[2];
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+        mn[k] = wave_min(mn[k]);
+        mx[k] = wave_max(mx[k]);
+    }
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & (DCSG_WAVE - 1)) == 0) {
+        for (int k = 0; k < 3; k++) {
+            atomicMin(&result[k], mn[k]);
+            atomicMax(&result[3 + k], mx[k]);
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(result + 8), (unsigned long long)cnt);
+    }
+}
+
+// Projection: consecutive vertices of the triangle buffer come from the same or neighbouring octree leaves,
+// so a wave's 64 vertices form a small cluster; the list is rebuilt every step because the vertices move.
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ verts, unsigned int n_verts, int steps)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    unsigned short* list = dcsg_wave_list(s, n_vec4);
+    const unsigned int tiles = (n_verts + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        unsigned int i = tile * DCSG_BLOCK + threadIdx.x;
+        bool valid = i < n_verts;
+        unsigned int j = valid ? i : 0u;
+        float x = verts[(size_t)j * 3 + 0], y = verts[(size_t)j * 3 + 1], z = verts[(size_t)j * 3 + 2];
+        for (int k = 0; k < steps; k++) {
+            int n_list = dcsg_build_active_list(s, valid, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list);
+            float sd, nx, ny, nz;
+            dcsg_stencil<4>(s, x, y, z, true, true, sd, nx, ny, nz, list, n_list);
+            float m = -sd;
+            x = x + m * nx;
+            y = y + m * ny;
+            z = z + m * nz;
+        }
+        if (valid) {
+            verts[(size_t)i * 3 + 0] = x;
+            verts[(size_t)i * 3 + 1] = y;
+            verts[(size_t)i * 3 + 2] = z;
+        }
+    }
+}
 #endif
 
 // Diagnostic: dcsg_sqrt over an array (exhaustive test of the custom square root).

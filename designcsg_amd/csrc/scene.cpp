@@ -120,7 +120,12 @@ bool parse_scene(const char* scene_txt, const char* bp_txt, Scene& s, std::strin
     return true;
 }
 
-size_t Scene::lds_bytes() const { return blob.size() * 4 + (size_t)n_regs * DCSG_BLOCK * sizeof(float); }
+size_t Scene::lds_bytes() const
+{
+    // blob + generic interpreter stack + per-wave active-step lists of the culling kernels (u16, 4 waves)
+    size_t lists = (size_t)(DCSG_BLOCK / DCSG_WAVE) * (((size_t)n_stack_prog + 7) & ~(size_t)7) * sizeof(uint16_t);
+    return blob.size() * 4 + (size_t)n_regs * DCSG_BLOCK * sizeof(float) + ((lists + 15) & ~(size_t)15);
+}
 
 namespace {
 struct Step {
@@ -344,12 +349,20 @@ void build_blob(Scene& s, bool null_brush_is_const)
         s.blob.push_back(f2u(s.pos[3 * i + 1]));
         s.blob.push_back(f2u(s.pos[3 * i + 2]));
         s.blob.push_back((uint32_t)s.shape[i]);
+        // Lipschitz bound of v -> (dot(v-o,right), dot(v-o,up), dot(v-o,forward)): the spectral norm of the matrix
+        // with those rows is at most its Frobenius norm (rounded up); used by the tile culling only.
+        double fro = 0;
+        for (int k = 0; k < 3; k++)
+            fro += (double)s.right[3 * i + k] * s.right[3 * i + k] + (double)s.up[3 * i + k] * s.up[3 * i + k] +
+                   (double)s.fwd[3 * i + k] * s.fwd[3 * i + k];
+        float lip = (float)(std::sqrt(fro) * (1.0 + 1e-6)) + 1e-30f;
         const std::vector<float>* axes[3] = {&s.right, &s.up, &s.fwd};
+        int ai = 0;
         for (auto* a : axes) {
             s.blob.push_back(f2u((*a)[3 * i]));
             s.blob.push_back(f2u((*a)[3 * i + 1]));
             s.blob.push_back(f2u((*a)[3 * i + 2]));
-            s.blob.push_back(0u);
+            s.blob.push_back(ai++ == 0 ? f2u(lip) : 0u);
         }
     }
 }

@@ -93,7 +93,8 @@ int dcsg_load_scene(dcsg_ctx* ctx, const char* scene_txt, const char* buildproce
 int dcsg_set_arbitrary_data(dcsg_ctx* ctx, const float* data, size_t items);
 /* Scene facts after loading: object / build-step counts, interpreter registers in use, whether scene.cl
  * was compiled (1) or the HIP-native brush bank applies (0), which interpreter runs the evaluation
- * kernels (0 generic LDS stack, 1 register stack depth <= 4, 2 depth <= 8, 3 per-scene specialised code)
+ * kernels (0 generic LDS stack, 1 register stack depth <= 4, 2 depth <= 8, 3 per-scene specialised code,
+ * 4 register stack with tile culling)
  * and the program's stack depth
  * (0 when it is not stack-disciplined).  Any out pointer may be NULL. */
 int dcsg_scene_info(const dcsg_ctx* ctx, int* n_objects, int* n_steps, int* n_slots, int* jit_compiled,

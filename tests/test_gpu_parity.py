@@ -55,13 +55,17 @@ def test_point_eval_bit_exact(ev, oracle, name, interpreter, monkeypatch):
     runs the build procedure exactly as buildprocedure.txt states it."""
     if interpreter == "stack":
         monkeypatch.setenv("DCSG_SPECIALISE", "0")
+        monkeypatch.setenv("DCSG_CULL", "0")
     if interpreter == "generic":
         monkeypatch.setenv("DCSG_SPECIALISE", "0")
+        monkeypatch.setenv("DCSG_CULL", "0")
         monkeypatch.setenv("DCSG_FORCE_VARIANT", "0")
     load(ev, name)
     info = ev.scene_info()
     assert info["stack_depth"] == EXPECTED_STACK_DEPTH[name]
-    want_variant = {"auto": 3 if name in SPECIALISED else 1, "stack": 1, "generic": 0}[interpreter]
+    # flat256 (flat program, built-in brushes, 257 objects) gets the tile-culling kernels by default
+    auto = 3 if name in SPECIALISED else (4 if name == "flat256" else 1)
+    want_variant = {"auto": auto, "stack": 1, "generic": 0}[interpreter]
     assert info["interpreter"] == want_variant
     osc = oracle.Scene.from_dir(scene_dir(name))
     rng = np.random.default_rng(7)
@@ -90,12 +94,21 @@ def test_builtin_bank_equals_jit_bank(ev, oracle):
     assert np.array_equal(bits(a), bits(b))
 
 
-@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table"])
+@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table", "flat256"])
 def test_lattice_sweep_bit_exact(ev, oracle, name):
     load(ev, name)
     osc = oracle.Scene.from_dir(scene_dir(name))
     center, diameter, _ = osc.estimate_bounding_box(10.0)
     res = 48  # not a power of two: exercises the x/w division path
+    if name == "flat256":  # 257 objects: keep the oracle's share of the run short; culling kernels on the GPU
+        assert ev.scene_info()["interpreter"] == 4
+        for r in (24, 32):
+            gs, gn = ev.eval_lattice(center, diameter[0], r)
+            ws, wn = osc.eval_lattice(center, diameter[0], r)
+            assert np.array_equal(bits(gs), bits(ws)) and np.array_equal(bits(gn), bits(wn))
+        gs2, _ = ev.eval_lattice(center, diameter[0], 32, normals=False)  # SDF-only path of the same kernel
+        assert np.array_equal(bits(gs2), bits(ws))
+        return
     for r in (res, 64):
         gs, gn = ev.eval_lattice(center, diameter[0], r)
         ws, wn = osc.eval_lattice(center, diameter[0], r)
@@ -114,7 +127,7 @@ GOLD_BBOX = {  # centre, diameter, interior points
 }
 
 
-@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups"])
+@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups", "flat256"])
 def test_bounding_box_stage(ev, oracle, name):
     load(ev, name)
     c, d, n = ev.estimate_bounding_box(10.0)
