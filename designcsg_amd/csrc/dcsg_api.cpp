@@ -295,6 +295,10 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
         unsigned first = (unsigned)(p0 * plane);
         unsigned cnt = (unsigned)(np * plane);
         unsigned work = pairs ? (unsigned)(((np + 1) / 2) * plane) : cnt;
+        if (c->variant == 4) {  // 8 x 8 x 4 bricks, one per 256-thread block iteration
+            uint64_t b8 = (n1 + 7) / 8;
+            work = (unsigned)(b8 * b8 * ((np + 3) / 4) * DCSG_BLOCK);
+        }
         unsigned tiles = (work + DCSG_BLOCK - 1) / DCSG_BLOCK;
         void* args[] = {(void*)&blob, &nv, &L, &z0, &first, &cnt, (void*)&d_sdf, (void*)&d_nrm};
         int r = launch(c, fn, sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), s, args);

@@ -489,6 +489,81 @@ __device__ __forceinline__ float wave_max_f(float v)
     return v;
 }
 
+// The interval [lo, hi] of the accumulator evolves by clamps x -> min(max(x, P), Q): T_min with a value in
+// [lb, ub] maps lo by (P,Q) = (-inf, lb) and hi by (-inf, ub); T_max by (lb, +inf) / (ub, +inf); T_max(-s) by
+// (-ub, +inf) / (-lb, +inf); PUSH is the constant clamp (lb, lb) / (ub, ub).  Clamps are closed under
+// composition -- (p1,q1) then (p2,q2) is (max(p1,p2), min(max(q1,p2), q2)) -- so the interval before every step
+// is an exclusive prefix scan, and the kept steps are compacted with a ballot: no sequential walk.
+struct DcsgClamp2 {
+    float plo, qlo, phi, qhi;  // clamp acting on lo, clamp acting on hi
+};
+__device__ __forceinline__ DcsgClamp2 dcsg_clamp_identity()
+{
+    const float inf = __builtin_inff();
+    return {-inf, inf, -inf, inf};
+}
+// `a` first, then `b`
+__device__ __forceinline__ DcsgClamp2 dcsg_clamp_compose(const DcsgClamp2& a, const DcsgClamp2& b)
+{
+    return {fmaxf(a.plo, b.plo), fminf(fmaxf(a.qlo, b.plo), b.qlo), fmaxf(a.phi, b.phi), fminf(fmaxf(a.qhi, b.phi), b.qhi)};
+}
+__device__ __forceinline__ DcsgClamp2 dcsg_clamp_shfl_up(const DcsgClamp2& v, int o)
+{
+    return {__shfl_up(v.plo, o, DCSG_WAVE), __shfl_up(v.qlo, o, DCSG_WAVE), __shfl_up(v.phi, o, DCSG_WAVE),
+            __shfl_up(v.qhi, o, DCSG_WAVE)};
+}
+// inclusive scan of clamps across the 64 lanes of a wave (lane order = program order)
+__device__ __forceinline__ DcsgClamp2 dcsg_clamp_wave_scan(DcsgClamp2 v)
+{
+    const int lane = threadIdx.x & (DCSG_WAVE - 1);
+    for (int o = 1; o < DCSG_WAVE; o <<= 1) {
+        DcsgClamp2 t = dcsg_clamp_shfl_up(v, o);
+        if (lane >= o) v = dcsg_clamp_compose(t, v);
+    }
+    return v;
+}
+
+// Bounds of step c over the tile (centre cx,cy,cz, radius R) as its clamp; op = -1 for "no step".
+__device__ __forceinline__ DcsgClamp2 dcsg_step_clamp(const SceneLds& s, int c, int n, float cx, float cy, float cz, float R,
+                                                      int& op, float& lb, float& ub)
+{
+    op = -1;
+    lb = ub = 0.0f;
+    DcsgClamp2 k = dcsg_clamp_identity();
+    if (c >= n) return k;
+    int4 st = s.stack_steps[c];
+    op = st.x;
+    if (op > SOP_ACC_NEGMAX) return k;
+    int shape = st.y & 0xff;
+    float val, L;
+    if (shape == 0 && (s.flags & 1)) {
+        val = (float)K2_MAX_DISTANCE;
+        L = 0.0f;
+    } else {
+        float4 q1 = s.obj[4 * st.z + 1];
+        val = dcsg_import(s, shape, st.z, cx, cy, cz);
+        L = q1.w;
+    }
+    float m = L * R * 1.0001f + 1e-3f + 1e-5f * __builtin_fabsf(val);
+    lb = val - m;
+    ub = val + m;
+    const float inf = __builtin_inff();
+    if (op == SOP_PUSH) k = {lb, lb, ub, ub};
+    else if (op == SOP_ACC_MIN) k = {-inf, lb, -inf, ub};
+    else if (op == SOP_ACC_MAX) k = {lb, inf, ub, inf};
+    else k = {-ub, inf, -lb, inf};  // T_max with -s, -s in [-ub, -lb]
+    return k;
+}
+
+// keep test of a step given the interval [lo, hi] of the accumulator before it
+__device__ __forceinline__ bool dcsg_step_keep(int op, float lb, float ub, float lo, float hi)
+{
+    if (op == SOP_ACC_MIN) return !(lb > hi);    // T_min(a, s) = a wherever a < s
+    if (op == SOP_ACC_MAX) return !(ub < lo);    // T_max(a, s) = a wherever a > s
+    if (op == SOP_ACC_NEGMAX) return !(-lb < lo);
+    return op >= 0;                              // PUSH, POP, EXPORT: always
+}
+
 // Builds the wave's active-step list for the tile that contains the valid lanes' points (x,y,z); `pad` is
 // added to every half extent (the stencil's epsilon).  Returns the number of steps kept (wave-uniform).
 __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool valid, float x, float y, float z, float pad,
@@ -503,58 +578,25 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
     float hx = 0.5f * (x1 - x0) + pad, hy = 0.5f * (y1 - y0) + pad, hz = 0.5f * (z1 - z0) + pad;
     float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
     const int n = s.n_stack_steps;
-    float lo = 0.0f, hi = 0.0f;
+    DcsgClamp2 carry = dcsg_clamp_identity();  // composition of all steps of earlier chunks
     int n_active = 0;
     for (int base = 0; base < n; base += DCSG_WAVE) {
-        int c = base + lane;
-        int op = -1;
-        float lb = 0.0f, ub = 0.0f;
-        if (c < n) {
-            int4 st = s.stack_steps[c];
-            op = st.x;
-            if (op <= SOP_ACC_NEGMAX) {
-                int shape = st.y & 0xff;
-                float val, L;
-                if (shape == 0 && (s.flags & 1)) {
-                    val = (float)K2_MAX_DISTANCE;
-                    L = 0.0f;
-                } else {
-                    float4 q1 = s.obj[4 * st.z + 1];
-                    val = dcsg_import(s, shape, st.z, cx, cy, cz);
-                    L = q1.w;
-                }
-                float m = L * R * 1.0001f + 1e-3f + 1e-5f * __builtin_fabsf(val);
-                lb = val - m;
-                ub = val + m;
-            }
-        }
-        int cnt = n - base < DCSG_WAVE ? n - base : DCSG_WAVE;
-        for (int l = 0; l < cnt; l++) {
-            int o = __builtin_amdgcn_readlane(op, l);
-            float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb), l));
-            float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ub), l));
-            bool keep = true;
-            if (o == SOP_PUSH) {
-                lo = b0;
-                hi = b1;
-            } else if (o == SOP_ACC_MIN) {
-                keep = !(b0 > hi);
-                lo = fminf(lo, b0);
-                hi = fminf(hi, b1);
-            } else if (o == SOP_ACC_MAX) {
-                keep = !(b1 < lo);
-                lo = fmaxf(lo, b0);
-                hi = fmaxf(hi, b1);
-            } else if (o == SOP_ACC_NEGMAX) {
-                keep = !(-b0 < lo);
-                lo = fmaxf(lo, -b1);
-                hi = fmaxf(hi, -b0);
-            }
-            if (keep) {
-                if (lane == 0) list[n_active] = (unsigned short)(base + l);
-                n_active++;
-            }
-        }
+        int op;
+        float lb, ub;
+        DcsgClamp2 mine = dcsg_step_clamp(s, base + lane, n, cx, cy, cz, R, op, lb, ub);
+        DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
+        DcsgClamp2 excl = dcsg_clamp_shfl_up(incl, 1);
+        if (lane == 0) excl = dcsg_clamp_identity();
+        DcsgClamp2 before = dcsg_clamp_compose(carry, excl);
+        // a program starts with PUSH, so the clamp before any accumulate is constant: apply it to 0
+        float lo = fminf(fmaxf(0.0f, before.plo), before.qlo), hi = fminf(fmaxf(0.0f, before.phi), before.qhi);
+        bool keep = dcsg_step_keep(op, lb, ub, lo, hi);
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) list[n_active + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(base + lane);
+        n_active += __popcll(mask);
+        DcsgClamp2 last = {__shfl(incl.plo, DCSG_WAVE - 1, DCSG_WAVE), __shfl(incl.qlo, DCSG_WAVE - 1, DCSG_WAVE),
+                           __shfl(incl.phi, DCSG_WAVE - 1, DCSG_WAVE), __shfl(incl.qhi, DCSG_WAVE - 1, DCSG_WAVE)};
+        carry = dcsg_clamp_compose(carry, last);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1270,30 +1312,102 @@ __device__ __forceinline__ unsigned short* dcsg_wave_list(const SceneLds& s, int
     return lists + (threadIdx.x / DCSG_WAVE) * cap;
 }
 
+// Block-level list for the lattice sweep: the block owns an 8 x 8 x 4 brick of lattice points (radius ~5 lattice
+// steps instead of the 32 of a 64-point run); every thread bounds one step, the clamps are scanned across the
+// block (wave scans + a 4-entry combine through LDS), kept steps are compacted with ballots.
+// LDS behind the generic stack: list[cap] u16, then 4 wave totals (clamp + count).
+__device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_vec4, float cx, float cy, float cz, float R,
+                                                     const unsigned short*& list_out)
+{
+    const int n = s.n_stack_steps;
+    const int cap = (n + 7) & ~7;
+    const int lane = threadIdx.x & (DCSG_WAVE - 1), wave = threadIdx.x / DCSG_WAVE;
+    unsigned short* list = reinterpret_cast<unsigned short*>(reinterpret_cast<float*>(dcsg_lds + n_vec4) + s.n_regs * DCSG_BLOCK);
+    float* wtot = reinterpret_cast<float*>(list + cap);  // [4 waves][4] clamp totals, then [4] counts (as int)
+    int* wcnt = reinterpret_cast<int*>(wtot + 16);
+    DcsgClamp2 carry = dcsg_clamp_identity();
+    int n_active = 0;
+    __syncthreads();  // the previous brick's readers are done with the list
+    for (int base = 0; base < n; base += DCSG_BLOCK) {
+        int op;
+        float lb, ub;
+        DcsgClamp2 mine = dcsg_step_clamp(s, base + threadIdx.x, n, cx, cy, cz, R, op, lb, ub);
+        DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
+        if (lane == DCSG_WAVE - 1) {
+            wtot[4 * wave + 0] = incl.plo;
+            wtot[4 * wave + 1] = incl.qlo;
+            wtot[4 * wave + 2] = incl.phi;
+            wtot[4 * wave + 3] = incl.qhi;
+        }
+        __syncthreads();
+        DcsgClamp2 pre = carry;  // everything before this wave: earlier chunks, then earlier waves of this chunk
+        for (int w = 0; w < wave; w++)
+            pre = dcsg_clamp_compose(pre, {wtot[4 * w], wtot[4 * w + 1], wtot[4 * w + 2], wtot[4 * w + 3]});
+        DcsgClamp2 excl = dcsg_clamp_shfl_up(incl, 1);
+        if (lane == 0) excl = dcsg_clamp_identity();
+        DcsgClamp2 before = dcsg_clamp_compose(pre, excl);
+        float lo = fminf(fmaxf(0.0f, before.plo), before.qlo), hi = fminf(fmaxf(0.0f, before.phi), before.qhi);
+        bool keep = dcsg_step_keep(op, lb, ub, lo, hi);
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+        if (lane == 0) wcnt[wave] = __popcll(mask);
+        for (int w = 0; w < DCSG_BLOCK / DCSG_WAVE; w++)
+            carry = dcsg_clamp_compose(carry, {wtot[4 * w], wtot[4 * w + 1], wtot[4 * w + 2], wtot[4 * w + 3]});
+        __syncthreads();
+        int off = n_active;
+        for (int w = 0; w < wave; w++) off += wcnt[w];
+        if (keep) list[off + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(base + threadIdx.x);
+        for (int w = 0; w < DCSG_BLOCK / DCSG_WAVE; w++) n_active += wcnt[w];
+        __syncthreads();  // list entries visible; wtot / wcnt free for the next chunk
+    }
+    list_out = list;
+    return __builtin_amdgcn_readfirstlane(n_active);
+}
+
+// Lattice sweep with block-brick culling.  The launch covers whole planes (first = multiple of (res+1)^2).
+// A wave writes 8 rows of 8 consecutive points (32-B / 96-B segments): this kernel is for scenes whose cost
+// is hundreds of object evaluations per point, where store shape is irrelevant next to the work removed.
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_sweep_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,
               unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
-    unsigned short* list = dcsg_wave_list(s, n_vec4);
     const unsigned int n1 = (unsigned int)L.res + 1u;
-    const unsigned int tiles = (n_points + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    const unsigned int plane = n1 * n1;
+    const unsigned int planes = dcsg_div_n1(L, dcsg_div_n1(L, n_points));
+    const unsigned int first_plane = dcsg_div_n1(L, dcsg_div_n1(L, first));
+    const unsigned int bx = (n1 + 7u) >> 3, by = (n1 + 7u) >> 3, bz = (planes + 3u) >> 2;
+    const unsigned int bricks = bx * by * bz;
     const float pad = nrm_out ? (float)K2_NORMAL_EPSILON * 1.01f : 0.0f;
-    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        unsigned int local = tile * DCSG_BLOCK + threadIdx.x;
-        bool valid = local < n_points;
-        unsigned int idx = first + (valid ? local : 0u);
-        unsigned int t = dcsg_div_n1(L, idx);
-        unsigned int ix = idx - t * n1;
-        unsigned int iz = dcsg_div_n1(L, t);
-        unsigned int iy = t - iz * n1;
-        float x = dcsg_lattice_coord(L, 0, (int)ix);
-        float y = dcsg_lattice_coord(L, 1, (int)iy);
-        float z = dcsg_lattice_coord(L, 2, (int)iz + z0);
-        int n_list = dcsg_build_active_list(s, valid, x, y, z, pad, list);
+    const unsigned int lx = threadIdx.x & 7u, ly = (threadIdx.x >> 3) & 7u, lz = threadIdx.x >> 6;
+    for (unsigned int brick = blockIdx.x; brick < bricks; brick += gridDim.x) {
+        unsigned int tx = brick % bx, t2 = brick / bx;
+        unsigned int ty = t2 % by, tz = t2 / by;
+        // brick bounds in lattice indices (clipped) -> centre and radius in world units
+        unsigned int ix0 = tx * 8u, iy0 = ty * 8u, izl0 = tz * 4u;
+        unsigned int ix1 = ix0 + 7u < n1 - 1u ? ix0 + 7u : n1 - 1u;
+        unsigned int iy1 = iy0 + 7u < n1 - 1u ? iy0 + 7u : n1 - 1u;
+        unsigned int izl1 = izl0 + 3u < planes - 1u ? izl0 + 3u : planes - 1u;
+        float xa = dcsg_lattice_coord(L, 0, (int)ix0), xb = dcsg_lattice_coord(L, 0, (int)ix1);
+        float ya = dcsg_lattice_coord(L, 1, (int)iy0), yb = dcsg_lattice_coord(L, 1, (int)iy1);
+        float za = dcsg_lattice_coord(L, 2, (int)(first_plane + izl0) + z0);
+        float zb = dcsg_lattice_coord(L, 2, (int)(first_plane + izl1) + z0);
+        float hx = 0.5f * __builtin_fabsf(xb - xa) + pad, hy = 0.5f * __builtin_fabsf(yb - ya) + pad,
+              hz = 0.5f * __builtin_fabsf(zb - za) + pad;
+        float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
+        const unsigned short* list;
+        int n_list = dcsg_build_block_list(s, n_vec4, 0.5f * (xa + xb), 0.5f * (ya + yb), 0.5f * (za + zb), R, list);
+
+        unsigned int ix = ix0 + lx, iy = iy0 + ly, izl = izl0 + lz;
+        bool valid = ix < n1 && iy < n1 && izl < planes;
+        // invalid lanes evaluate a clamped point (keeps the wave's control flow uniform) and store nothing
+        unsigned int cix = ix < n1 ? ix : n1 - 1u, ciy = iy < n1 ? iy : n1 - 1u, cizl = izl < planes ? izl : planes - 1u;
+        float x = dcsg_lattice_coord(L, 0, (int)cix);
+        float y = dcsg_lattice_coord(L, 1, (int)ciy);
+        float z = dcsg_lattice_coord(L, 2, (int)(first_plane + cizl) + z0);
         float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
         dcsg_stencil<4>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz, list, n_list);
         if (valid) {
+            unsigned int idx = first + izl * plane + iy * n1 + ix;
             if (sdf_out) sdf_out[idx] = sd;
             if (nrm_out) {
                 float* o = nrm_out + (size_t)idx * 3;

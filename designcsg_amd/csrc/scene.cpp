@@ -122,8 +122,9 @@ bool parse_scene(const char* scene_txt, const char* bp_txt, Scene& s, std::strin
 
 size_t Scene::lds_bytes() const
 {
-    // blob + generic interpreter stack + per-wave active-step lists of the culling kernels (u16, 4 waves)
-    size_t lists = (size_t)(DCSG_BLOCK / DCSG_WAVE) * (((size_t)n_stack_prog + 7) & ~(size_t)7) * sizeof(uint16_t);
+    // blob + generic interpreter stack + the culling kernels' work area: per step LB, UB (f32), list entry (u16),
+    // opcode (u8) and a counter -- also large enough for the 4 per-wave u16 lists of the projection kernel
+    size_t lists = (((size_t)n_stack_prog + 7) & ~(size_t)7) * 12 + 16;
     return blob.size() * 4 + (size_t)n_regs * DCSG_BLOCK * sizeof(float) + ((lists + 15) & ~(size_t)15);
 }
 
