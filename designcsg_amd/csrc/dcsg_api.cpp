@@ -971,7 +971,11 @@ int dcsg_export(dcsg_ctx* c, const char* cfg_txt, const char* stl_path, const ch
     const int res = 1 << cfg.grid_level;
     const size_t n1 = (size_t)res + 1, n_pts = n1 * n1 * n1;
     st.lattice_points = n_pts;
-    const bool dense_normals = (flags & DCSG_EXPORT_DENSE_NORMALS) != 0;
+    // Normals: swept densely with the SDF, or evaluated on demand by the mesher (its samples go through the generic
+    // interpreter, which visits every object).  Many-object scenes that run the culling kernels sweep densely:
+    // flat256 at 512^3 meshes in 0.8 ms after a 9.5 ms fused sweep instead of 37 ms after a 6 ms SDF sweep.
+    const bool dense_normals = (flags & DCSG_EXPORT_DENSE_NORMALS) != 0 ||
+                               (c->variant == 4 && !(flags & DCSG_EXPORT_SPARSE_NORMALS));
     if ((r = ensure(c, c->d_lat_sdf, n_pts * sizeof(float)))) return r;
     if (dense_normals && (r = ensure(c, c->d_lat_nrm, n_pts * 3 * sizeof(float)))) return r;
     float diam3[3] = {diameter, diameter, diameter};

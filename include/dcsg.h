@@ -150,7 +150,8 @@ int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* 
 /* MyFrame::OnExportInner (DesignCSG.cpp:638-790) end to end on one GPU: stage A, lattice sweep,
  * mesher, retopologize (identity), projection, both writers.
  * stl_path / ply_path may be NULL to skip a writer.  flags: DCSG_EXPORT_*. */
-#define DCSG_EXPORT_DENSE_NORMALS 1u /* sweep normals for every lattice point instead of on demand */
+#define DCSG_EXPORT_DENSE_NORMALS 1u  /* sweep normals for every lattice point instead of on demand */
+#define DCSG_EXPORT_SPARSE_NORMALS 2u /* never sweep normals densely (default: dense only for culled scenes) */
 int dcsg_export(dcsg_ctx* ctx, const char* export_config_txt, const char* stl_path, const char* ply_path,
                 unsigned flags, dcsg_export_stats* stats);
 
