@@ -38,6 +38,7 @@ DESIGNS = {
     "flat256": os.path.join(OWN_DESIGNS, "flat256.py"),
     "grouped256": os.path.join(OWN_DESIGNS, "grouped256.py"),
     "ad_table": os.path.join(OWN_DESIGNS, "ad_table.py"),
+    "prefabs": os.path.join(OWN_DESIGNS, "prefabs.py"),
 }
 FILES = ["scene.txt", "buildprocedure.txt", "scene.cl", "exportConfig.txt"]
 

@@ -115,3 +115,11 @@ def test_transform_conventions():
         sys.path.pop(0)
         for mod in ("scenecompiler", "DesignCSG", "designlibrary"):
             sys.modules.pop(mod, None)
+
+
+def test_prefab_helpers_against_reference_capture(tmp_path):
+    """drawComponent / eraseComponent / fabricate / apply_transform: a design using them must compile to the same
+    files under the own API as under the reference (captured in tests/golden/scenes/prefabs)."""
+    run(os.path.join(DESIGNS, "prefabs.py"), tmp_path)
+    for f in FILES:
+        assert (tmp_path / f).read_bytes() == open(os.path.join(SCENES, "prefabs", f), "rb").read(), f

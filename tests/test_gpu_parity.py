@@ -11,7 +11,7 @@ from conftest import export_config_text, read_scene, scene_dir
 
 pytestmark = pytest.mark.gpu
 
-ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table"]
+ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table", "prefabs"]
 STL_TOL = 1e-5  # north_star: ".stl diff within 1e-5"
 
 
@@ -41,10 +41,10 @@ def sorted_tris(t):
 
 
 EXPECTED_STACK_DEPTH = {"sphere": 1, "design1": 1, "design2": 1, "flat256": 1, "mixed_groups": 2, "grouped256": 2,
-                        "ad_table": 1}
+                        "ad_table": 1, "prefabs": 2}
 
 
-SPECIALISED = {"sphere", "design1", "design2", "mixed_groups", "ad_table"}  # <= 48 object evaluations
+SPECIALISED = {"sphere", "design1", "design2", "mixed_groups", "ad_table", "prefabs"}  # <= 48 object evaluations
 
 
 @pytest.mark.parametrize("interpreter", ["auto", "stack", "generic"])
