@@ -33,6 +33,8 @@ WORKLOADS = {
     "design2_512": ("design2", 9, [0.0, -0.0390625, 0.0], 9.3359375),
     "design2_1024": ("design2", 10, [0.0, -0.0390625, 0.0], 9.3359375),
     "flat256_512": ("flat256", 9, [0.0, 0.0, 0.0], 10.0),
+    "flat256_1024": ("flat256", 10, [0.0, 0.0, 0.0], 10.0),
+    "grouped256_512": ("grouped256", 9, [0.0, 0.0, 0.0], 10.0),
 }
 
 

@@ -465,18 +465,14 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     c->scene = std::move(s);
     const int depth = c->scene.n_stack_prog ? c->scene.stack_depth : 1000;
     c->variant = c->specialised ? 3 : (depth <= 4 ? 1 : (depth <= 8 ? 2 : 0));
-    // Tile culling: stand-alone module (built-in brushes), flat program (depth 1) with enough objects to pay off.
+    // Tile culling: stand-alone module (built-in brushes), program of top-level items (leaves and one level of
+    // groups), enough objects to pay off.
     {
         int n_evals = 0;
-        bool flat = c->scene.n_stack_prog > 0 && c->scene.stack_depth == 1;
-        for (int k = 0; k < c->scene.n_stack_prog; k++) {
-            int op = c->scene.stack_prog[4 * k];
-            n_evals += op <= 35 ? 1 : 0;
-            if (op >= 36 && op <= 38) flat = false;
-        }
+        for (int k = 0; k < c->scene.n_stack_prog; k++) n_evals += c->scene.stack_prog[4 * k] <= 35 ? 1 : 0;
         const char* env_cull = getenv("DCSG_CULL");
         int min_objects = env_cull ? atoi(env_cull) : 16;  // 0 disables
-        if (!c->jit && flat && min_objects > 0 && n_evals >= min_objects) c->variant = 4;
+        if (!c->jit && c->scene.n_items > 0 && min_objects > 0 && n_evals >= min_objects) c->variant = 4;
     }
     if (const char* force = getenv("DCSG_FORCE_VARIANT")) {  // A/B testing only; never exceeds what the program fits
         int f = atoi(force);

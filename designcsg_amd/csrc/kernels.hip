@@ -60,6 +60,41 @@ __device__ __forceinline__ float dcsg_sqrt(float x)
 }
 
 // ---------------------------------------------------------------------------
+// wave / block reductions and scans
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min(int v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(v, o, DCSG_WAVE);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(v, o, DCSG_WAVE);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned int wave_sum(unsigned int v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, DCSG_WAVE);
+    return v;
+}
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v)
+{
+    const int lane = threadIdx.x & (DCSG_WAVE - 1);
+    for (int o = 1; o < DCSG_WAVE; o <<= 1) {
+        unsigned int t = __shfl_up(v, o, DCSG_WAVE);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
 // Brush bank
 // ---------------------------------------------------------------------------
 #ifdef DCSG_EXTERN_BANK
@@ -118,7 +153,8 @@ __device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_
 // Blob (built by csrc/scene.cpp): [0] header {n_steps,n_objects,n_slots,flags}, flags bit 0 =
 // "brush 0 is the constant null brush `return MAX_DISTANCE;`" (always true for the built-in bank;
 // for a JIT-linked scene.cl only when the host verified sd0's body); [1] header
-// {n_stack_steps, stack_depth, 0, 0}; then the register program, the stack program, the objects:
+// {n_stack_steps, stack_depth, n_items, 0}; then the register program, the stack program, the culling
+// items, the objects:
 // steps {opcode,left,right,dest}; 4 x float4 per object:
 // {pos.xyz, shape_id bits}, {right.xyz,0}, {up.xyz,0}, {forward.xyz,0}.
 // After the blob: the interpreter stack, slot-major (slot*DCSG_BLOCK + tid), so
@@ -130,6 +166,8 @@ struct SceneLds {
     const int4* steps;
     const float4* obj;
     const int4* stack_steps;  // stack program (empty when the program does not nest)
+    const int4* items;        // top-level items of the stack program (tile culling)
+    int n_items;
     float* stack;  // generic interpreter's LDS stack, already offset by threadIdx.x
     int n_steps;
     int n_stack_steps;
@@ -149,8 +187,11 @@ __device__ __forceinline__ SceneLds dcsg_stage_scene(const uint4* __restrict__ b
     int n_stack = __builtin_amdgcn_readfirstlane((int)dcsg_lds[1].x);
     s.n_stack_steps = n_stack;
     s.steps = reinterpret_cast<const int4*>(dcsg_lds + 2);
+    int n_items = __builtin_amdgcn_readfirstlane((int)dcsg_lds[1].z);
+    s.n_items = n_items;
     s.stack_steps = reinterpret_cast<const int4*>(dcsg_lds + 2 + n_steps);
-    s.obj = reinterpret_cast<const float4*>(dcsg_lds + 2 + n_steps + n_stack);
+    s.items = reinterpret_cast<const int4*>(dcsg_lds + 2 + n_steps + n_stack);
+    s.obj = reinterpret_cast<const float4*>(dcsg_lds + 2 + n_steps + n_stack + n_items);
     s.stack = reinterpret_cast<float*>(dcsg_lds + n_vec4) + threadIdx.x;
     return s;
 }
@@ -523,17 +564,10 @@ __device__ __forceinline__ DcsgClamp2 dcsg_clamp_wave_scan(DcsgClamp2 v)
     return v;
 }
 
-// Bounds of step c over the tile (centre cx,cy,cz, radius R) as its clamp; op = -1 for "no step".
-__device__ __forceinline__ DcsgClamp2 dcsg_step_clamp(const SceneLds& s, int c, int n, float cx, float cy, float cz, float R,
-                                                      int& op, float& lb, float& ub)
+// value of one PUSH / ACC step at the tile centre with its margin: s in [lb, ub] over the tile
+__device__ __forceinline__ void dcsg_step_bounds(const SceneLds& s, const int4& st, float cx, float cy, float cz, float R,
+                                                 float& lb, float& ub)
 {
-    op = -1;
-    lb = ub = 0.0f;
-    DcsgClamp2 k = dcsg_clamp_identity();
-    if (c >= n) return k;
-    int4 st = s.stack_steps[c];
-    op = st.x;
-    if (op > SOP_ACC_NEGMAX) return k;
     int shape = st.y & 0xff;
     float val, L;
     if (shape == 0 && (s.flags & 1)) {
@@ -547,7 +581,52 @@ __device__ __forceinline__ DcsgClamp2 dcsg_step_clamp(const SceneLds& s, int c, 
     float m = L * R * 1.0001f + 1e-3f + 1e-5f * __builtin_fabsf(val);
     lb = val - m;
     ub = val + m;
+}
+
+// Bounds of top-level item i over the tile (centre cx,cy,cz, radius R) and the clamp it applies to the root
+// accumulator's interval.  A leaf is one accumulate step; a group "PUSH, ACC..., POP_x" is walked step by step
+// (interval arithmetic on its own accumulator) and then acts like an accumulate of its result with the POP's
+// operator.  op = -1 for "no item"; first/count = the item's steps.
+__device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, float cx, float cy, float cz, float R, int& op,
+                                                      float& lb, float& ub, int& first, int& count)
+{
+    op = -1;
+    lb = ub = 0.0f;
+    first = count = 0;
+    DcsgClamp2 k = dcsg_clamp_identity();
+    if (i >= s.n_items) return k;
+    int4 it = s.items[i];
+    first = it.x;
+    count = it.y;
+    op = it.z;
     const float inf = __builtin_inff();
+    if (op == SOP_EXPORT_TOP) return k;
+    if (count == 1) {
+        dcsg_step_bounds(s, s.stack_steps[first], cx, cy, cz, R, lb, ub);
+    } else {
+        float glo = 0.0f, ghi = 0.0f;
+        for (int j = 0; j < count - 1; j++) {
+            int4 st = s.stack_steps[first + j];
+            float b0, b1;
+            dcsg_step_bounds(s, st, cx, cy, cz, R, b0, b1);
+            if (st.x == SOP_PUSH) {
+                glo = b0;
+                ghi = b1;
+            } else if (st.x == SOP_ACC_MIN) {
+                glo = fminf(glo, b0);
+                ghi = fminf(ghi, b1);
+            } else if (st.x == SOP_ACC_MAX) {
+                glo = fmaxf(glo, b0);
+                ghi = fmaxf(ghi, b1);
+            } else {
+                glo = fmaxf(glo, -b1);
+                ghi = fmaxf(ghi, -b0);
+            }
+        }
+        lb = glo;
+        ub = ghi;
+        op = op - (SOP_POP_MIN - SOP_ACC_MIN);  // POP_x joins like ACC_x
+    }
     if (op == SOP_PUSH) k = {lb, lb, ub, ub};
     else if (op == SOP_ACC_MIN) k = {-inf, lb, -inf, ub};
     else if (op == SOP_ACC_MAX) k = {lb, inf, ub, inf};
@@ -577,13 +656,13 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
     float cx = 0.5f * (x0 + x1), cy = 0.5f * (y0 + y1), cz = 0.5f * (z0 + z1);
     float hx = 0.5f * (x1 - x0) + pad, hy = 0.5f * (y1 - y0) + pad, hz = 0.5f * (z1 - z0) + pad;
     float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
-    const int n = s.n_stack_steps;
-    DcsgClamp2 carry = dcsg_clamp_identity();  // composition of all steps of earlier chunks
+    const int n = s.n_items;
+    DcsgClamp2 carry = dcsg_clamp_identity();  // composition of all items of earlier chunks
     int n_active = 0;
     for (int base = 0; base < n; base += DCSG_WAVE) {
-        int op;
+        int op, first, count;
         float lb, ub;
-        DcsgClamp2 mine = dcsg_step_clamp(s, base + lane, n, cx, cy, cz, R, op, lb, ub);
+        DcsgClamp2 mine = dcsg_item_clamp(s, base + lane, cx, cy, cz, R, op, lb, ub, first, count);
         DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
         DcsgClamp2 excl = dcsg_clamp_shfl_up(incl, 1);
         if (lane == 0) excl = dcsg_clamp_identity();
@@ -591,9 +670,11 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
         // a program starts with PUSH, so the clamp before any accumulate is constant: apply it to 0
         float lo = fminf(fmaxf(0.0f, before.plo), before.qlo), hi = fminf(fmaxf(0.0f, before.phi), before.qhi);
         bool keep = dcsg_step_keep(op, lb, ub, lo, hi);
-        unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) list[n_active + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(base + lane);
-        n_active += __popcll(mask);
+        unsigned int sz = keep ? (unsigned int)count : 0u;
+        unsigned int inc = wave_scan_incl(sz);
+        unsigned int off = (unsigned int)n_active + inc - sz;
+        for (unsigned int j = 0; j < sz; j++) list[off + j] = (unsigned short)(first + (int)j);
+        n_active += (int)__shfl(inc, DCSG_WAVE - 1, DCSG_WAVE);
         DcsgClamp2 last = {__shfl(incl.plo, DCSG_WAVE - 1, DCSG_WAVE), __shfl(incl.qlo, DCSG_WAVE - 1, DCSG_WAVE),
                            __shfl(incl.phi, DCSG_WAVE - 1, DCSG_WAVE), __shfl(incl.qhi, DCSG_WAVE - 1, DCSG_WAVE)};
         carry = dcsg_clamp_compose(carry, last);
@@ -847,41 +928,6 @@ DCSG_EVAL_KERNEL(dcsg_eval_points_s8, 8)
 #ifdef DCSG_HAVE_SPEC
 DCSG_EVAL_KERNEL(dcsg_eval_points_sp, -1)
 #endif
-
-// ---------------------------------------------------------------------------
-// wave / block reductions and scans
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ int wave_min(int v)
-{
-    for (int o = 32; o > 0; o >>= 1) {
-        int t = __shfl_xor(v, o, DCSG_WAVE);
-        v = t < v ? t : v;
-    }
-    return v;
-}
-__device__ __forceinline__ int wave_max(int v)
-{
-    for (int o = 32; o > 0; o >>= 1) {
-        int t = __shfl_xor(v, o, DCSG_WAVE);
-        v = t > v ? t : v;
-    }
-    return v;
-}
-__device__ __forceinline__ unsigned int wave_sum(unsigned int v)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, DCSG_WAVE);
-    return v;
-}
-// inclusive prefix sum across the 64 lanes of a wave
-__device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v)
-{
-    const int lane = threadIdx.x & (DCSG_WAVE - 1);
-    for (int o = 1; o < DCSG_WAVE; o <<= 1) {
-        unsigned int t = __shfl_up(v, o, DCSG_WAVE);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
 
 // ---------------------------------------------------------------------------
 // Kernel 3: stage A bounding-box probe, DesignCSG.cpp:668-712.
@@ -1319,8 +1365,8 @@ __device__ __forceinline__ unsigned short* dcsg_wave_list(const SceneLds& s, int
 __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_vec4, float cx, float cy, float cz, float R,
                                                      const unsigned short*& list_out)
 {
-    const int n = s.n_stack_steps;
-    const int cap = (n + 7) & ~7;
+    const int n = s.n_items;
+    const int cap = (s.n_stack_steps + 7) & ~7;
     const int lane = threadIdx.x & (DCSG_WAVE - 1), wave = threadIdx.x / DCSG_WAVE;
     unsigned short* list = reinterpret_cast<unsigned short*>(reinterpret_cast<float*>(dcsg_lds + n_vec4) + s.n_regs * DCSG_BLOCK);
     float* wtot = reinterpret_cast<float*>(list + cap);  // [4 waves][4] clamp totals, then [4] counts (as int)
@@ -1329,9 +1375,9 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
     int n_active = 0;
     __syncthreads();  // the previous brick's readers are done with the list
     for (int base = 0; base < n; base += DCSG_BLOCK) {
-        int op;
+        int op, first, count;
         float lb, ub;
-        DcsgClamp2 mine = dcsg_step_clamp(s, base + threadIdx.x, n, cx, cy, cz, R, op, lb, ub);
+        DcsgClamp2 mine = dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count);
         DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
         if (lane == DCSG_WAVE - 1) {
             wtot[4 * wave + 0] = incl.plo;
@@ -1348,14 +1394,15 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
         DcsgClamp2 before = dcsg_clamp_compose(pre, excl);
         float lo = fminf(fmaxf(0.0f, before.plo), before.qlo), hi = fminf(fmaxf(0.0f, before.phi), before.qhi);
         bool keep = dcsg_step_keep(op, lb, ub, lo, hi);
-        unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-        if (lane == 0) wcnt[wave] = __popcll(mask);
+        unsigned int sz = keep ? (unsigned int)count : 0u;
+        unsigned int inc = wave_scan_incl(sz);
+        if (lane == DCSG_WAVE - 1) wcnt[wave] = (int)inc;
         for (int w = 0; w < DCSG_BLOCK / DCSG_WAVE; w++)
             carry = dcsg_clamp_compose(carry, {wtot[4 * w], wtot[4 * w + 1], wtot[4 * w + 2], wtot[4 * w + 3]});
         __syncthreads();
-        int off = n_active;
-        for (int w = 0; w < wave; w++) off += wcnt[w];
-        if (keep) list[off + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(base + threadIdx.x);
+        unsigned int off = (unsigned int)n_active + inc - sz;
+        for (int w = 0; w < wave; w++) off += (unsigned int)wcnt[w];
+        for (unsigned int j = 0; j < sz; j++) list[off + j] = (unsigned short)(first + (int)j);
         for (int w = 0; w < DCSG_BLOCK / DCSG_WAVE; w++) n_active += wcnt[w];
         __syncthreads();  // list entries visible; wtot / wcnt free for the next chunk
     }

@@ -258,6 +258,40 @@ void optimise_program(Scene& s)
             s.n_stack_prog = (int)sp.size();
             s.stack_depth = depth_max;
         }
+        // items: what the root accumulator sees -- single accumulate steps and whole groups
+        s.items.clear();
+        s.n_items = 0;
+        if (ok && depth_max <= 2) {
+            bool fine = true;
+            for (size_t k = 0; k < sp.size() && fine;) {
+                const Step& t = sp[k];
+                if (t.op == PUSH && t.d == 0) {
+                    s.items.insert(s.items.end(), {(int)k, 1, PUSH, 0});
+                    k++;
+                } else if (t.op >= ACC_MIN && t.op <= ACC_NEGMAX && t.d == 1) {
+                    s.items.insert(s.items.end(), {(int)k, 1, t.op, 0});
+                    k++;
+                } else if (t.op == PUSH && t.d == 1) {
+                    size_t e = k + 1;
+                    while (e < sp.size() && !(sp[e].op >= POP_MIN && sp[e].op <= POP_NEGMAX)) {
+                        if (!(sp[e].op >= ACC_MIN && sp[e].op <= ACC_NEGMAX)) fine = false;
+                        e++;
+                    }
+                    if (e >= sp.size()) fine = false;
+                    if (fine) s.items.insert(s.items.end(), {(int)k, (int)(e - k + 1), sp[e].op, 0});
+                    k = e + 1;
+                } else if (t.op == EXPORT_TOP) {
+                    s.items.insert(s.items.end(), {(int)k, 1, EXPORT_TOP, 0});
+                    k++;
+                } else {
+                    fine = false;
+                }
+            }
+            if (fine)
+                s.n_items = (int)(s.items.size() / 4);
+            else
+                s.items.clear();
+        }
     }
     // ---- liveness renaming ---------------------------------------------------------------------
     const int NV = DCSG_MAX_SLOTS;
@@ -341,10 +375,11 @@ void build_blob(Scene& s, bool null_brush_is_const)
     s.blob.push_back(null_brush_is_const ? 1u : 0u);
     s.blob.push_back((uint32_t)s.n_stack_prog);
     s.blob.push_back((uint32_t)s.stack_depth);
-    s.blob.push_back(0u);
+    s.blob.push_back((uint32_t)s.n_items);
     s.blob.push_back(0u);
     for (int c = 0; c < 4 * s.n_prog; c++) s.blob.push_back((uint32_t)s.prog[c]);
     for (int c = 0; c < 4 * s.n_stack_prog; c++) s.blob.push_back((uint32_t)s.stack_prog[c]);
+    for (int c = 0; c < 4 * s.n_items; c++) s.blob.push_back((uint32_t)s.items[c]);
     for (int i = 0; i < s.n_objects; i++) {
         s.blob.push_back(f2u(s.pos[3 * i]));
         s.blob.push_back(f2u(s.pos[3 * i + 1]));

@@ -21,6 +21,11 @@ struct Scene {
     int n_regs = 0;                            // stack registers prog needs (<= n_slots)
     std::vector<int32_t> stack_prog;           // stack program (kernels.hip SOP_*), empty if prog does not nest
     int n_stack_prog = 0, stack_depth = 0;
+    // Top-level items of the stack program for the tile culling (kernels.hip): {first step, step count, kind, 0};
+    // kind = the accumulate opcode a leaf step applies (33..35), the POP opcode a group is joined with (36..38),
+    // 32 for the root PUSH, 39 for EXPORT_TOP.  Empty when the program is deeper than one group level.
+    std::vector<int32_t> items;
+    int n_items = 0;
     int max_brush_id = 0;                      // over IMPORT steps
     std::vector<uint32_t> blob;                // uint4-granular, see kernels.hip "Scene tables in LDS"
     int blob_vec4() const { return (int)(blob.size() / 4); }
