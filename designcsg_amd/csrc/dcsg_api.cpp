@@ -37,6 +37,7 @@ struct Kernels {
     hipFunction_t sweep[5] = {}, eval_points[5] = {}, bbox[5] = {}, project[5] = {};
     hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr;
     hipFunction_t sweep_sp2 = nullptr;  // specialised sweep, two planes per thread (scene modules only)
+    hipFunction_t dd_insert = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
 };
 
 double now_s()
@@ -62,8 +63,9 @@ struct dcsg_ctx {
     std::vector<float> ad_host;
     std::vector<uint8_t> tri_table;
     DevBuf d_blob, d_ad, d_tri_table, d_pts, d_out, d_nodes[2], d_info, d_block_sums, d_small, d_tris, d_lat_sdf,
-        d_lat_nrm;
+        d_lat_nrm, d_dd_table, d_dd_rep, d_dd_slot, d_dd_compact;
     uint64_t n_tris = 0;
+    uint64_t last_unique_vertices = 0;  // distinct positions projected by the last dcsg_project_triangles
     void* h_pinned = nullptr;  // host staging for triangle downloads
     size_t h_pinned_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -134,7 +136,9 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
         const char* name;
         hipFunction_t* f;
     } tab[] = {{"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan}, {"dcsg_mesh_emit", &k.emit},
-               {"dcsg_test_sqrt", &k.test_sqrt}};
+               {"dcsg_test_sqrt", &k.test_sqrt},       {"dcsg_dedup_insert", &k.dd_insert},
+               {"dcsg_dedup_count", &k.dd_count},      {"dcsg_dedup_gather", &k.dd_gather},
+               {"dcsg_dedup_scatter", &k.dd_scatter}};
     for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
     if (!scene_module) {
         HIPCHK(c, hipModuleGetFunction(&k.sweep[4], mod, "dcsg_sweep_c4"));
@@ -382,7 +386,7 @@ void dcsg_destroy(dcsg_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_blob,  &c->d_ad,         &c->d_tri_table, &c->d_pts,  &c->d_out,     &c->d_nodes[0],
                       &c->d_nodes[1], &c->d_info,    &c->d_block_sums, &c->d_small, &c->d_tris, &c->d_lat_sdf,
-                      &c->d_lat_nrm};
+                      &c->d_lat_nrm, &c->d_dd_table, &c->d_dd_rep, &c->d_dd_slot, &c->d_dd_compact};
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->scene_mod) hipModuleUnload(c->scene_mod);
@@ -752,10 +756,64 @@ int dcsg_project_vertices_device(dcsg_ctx* c, float* d_xyz, size_t n_vertices, i
     return launch(c, c->k->project[c->variant], sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), (hipStream_t)stream, args);
 }
 
+// performGradientDescent on the context's triangle buffer.  Copies of one position move identically, so one
+// representative per distinct position is projected (kernels.hip, "Vertex de-duplication") and copied back.
 int dcsg_project_triangles(dcsg_ctx* c, int steps, void* stream)
 {
     if (!c) return DCSG_ERR_INVALID;
-    return dcsg_project_vertices_device(c, (float*)c->d_tris.p, (size_t)c->n_tris * 3, steps, stream);
+    const size_t n_verts = (size_t)c->n_tris * 3;
+    const char* env = getenv("DCSG_DEDUP");
+    if (steps <= 0 || n_verts < 4096 || n_verts > 0x7fffffffull || (env && atoi(env) == 0))
+        return dcsg_project_vertices_device(c, (float*)c->d_tris.p, n_verts, steps, stream);
+    int r = need_scene(c);
+    if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned n = (unsigned)n_verts, n_blocks = (n + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    unsigned table_size = 1;
+    while (table_size < 2 * n) table_size <<= 1;
+    unsigned mask = table_size - 1;
+    if ((r = ensure(c, c->d_dd_table, (size_t)table_size * 4))) return r;
+    if ((r = ensure(c, c->d_dd_rep, (size_t)n * 4))) return r;
+    if ((r = ensure(c, c->d_dd_slot, (size_t)n * 4))) return r;
+    if ((r = ensure(c, c->d_block_sums, (size_t)n_blocks * 2 * sizeof(unsigned)))) return r;
+    if ((r = ensure(c, c->d_small, 4096))) return r;
+    HIPCHK(c, hipMemsetAsync(c->d_dd_table.p, 0xff, (size_t)table_size * 4, s));
+    float* verts = (float*)c->d_tris.p;
+    unsigned* table = (unsigned*)c->d_dd_table.p;
+    unsigned* rep = (unsigned*)c->d_dd_rep.p;
+    unsigned* slot = (unsigned*)c->d_dd_slot.p;
+    unsigned* bs = (unsigned*)c->d_block_sums.p;
+    unsigned* totals = (unsigned*)c->d_small.p;
+    unsigned grid = sweep_grid(c, n_blocks);
+    {
+        void* args[] = {(void*)&verts, &n, (void*)&table, &mask, (void*)&rep};
+        if ((r = launch(c, c->k->dd_insert, grid, DCSG_BLOCK, 0, s, args))) return r;
+    }
+    {
+        void* args[] = {(void*)&rep, &n, (void*)&bs};
+        if ((r = launch(c, c->k->dd_count, n_blocks, DCSG_BLOCK, 0, s, args))) return r;
+    }
+    {
+        void* args[] = {(void*)&bs, &n_blocks, (void*)&totals};
+        if ((r = launch(c, c->k->scan, 1, 1024, 0, s, args))) return r;
+    }
+    unsigned tot[2];
+    HIPCHK(c, hipMemcpyAsync(tot, totals, sizeof(tot), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    unsigned n_unique = tot[0];
+    if ((r = ensure(c, c->d_dd_compact, (size_t)(n_unique ? n_unique : 1) * 3 * sizeof(float)))) return r;
+    float* compact = (float*)c->d_dd_compact.p;
+    {
+        void* args[] = {(void*)&verts, (void*)&rep, &n, (void*)&bs, (void*)&compact, (void*)&slot};
+        if ((r = launch(c, c->k->dd_gather, n_blocks, DCSG_BLOCK, 0, s, args))) return r;
+    }
+    if ((r = dcsg_project_vertices_device(c, compact, n_unique, steps, stream))) return r;
+    {
+        void* args[] = {(void*)&verts, (void*)&rep, (void*)&slot, (void*)&compact, &n};
+        if ((r = launch(c, c->k->dd_scatter, grid, DCSG_BLOCK, 0, s, args))) return r;
+    }
+    c->last_unique_vertices = n_unique;
+    return 0;
 }
 
 int dcsg_triangles_device(dcsg_ctx* c, const float** d_triangles, uint64_t* n)

@@ -1540,6 +1540,101 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
 }
 #endif
 
+// ---------------------------------------------------------------------------
+// Vertex de-duplication for the projection.  The mesher emits an un-indexed triangle soup like the reference
+// (mesh.hpp:283-307), so every surface vertex appears about six times; performGradientDescent moves each copy
+// by the same function of its position (mesh.hpp:564-570), so projecting one representative per distinct
+// position and copying the result is exact.  Keys are the three float bit patterns; open addressing with
+// atomicCAS; the owner of a position is whichever copy claims its slot first (the value written back is the
+// same for any choice).  Owners are compacted in buffer order, which keeps neighbours in the mesh neighbours in
+// the compact list (spatial coherence for the tile culling).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int dcsg_hash3(unsigned int a, unsigned int b, unsigned int c)
+{
+    unsigned int h = a * 0x9E3779B1u;
+    h = (h ^ (h >> 15)) + b * 0x85EBCA77u;
+    h = (h ^ (h >> 13)) + c * 0xC2B2AE3Du;
+    h ^= h >> 16;
+    return h * 0x27D4EB2Fu;
+}
+
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_dedup_insert(const float* __restrict__ verts, unsigned int n, unsigned int* __restrict__ table, unsigned int mask,
+                  unsigned int* __restrict__ rep)
+{
+    const unsigned int* vb = reinterpret_cast<const unsigned int*>(verts);
+    for (unsigned int v = blockIdx.x * DCSG_BLOCK + threadIdx.x; v < n; v += gridDim.x * DCSG_BLOCK) {
+        unsigned int a = vb[(size_t)v * 3], b = vb[(size_t)v * 3 + 1], c = vb[(size_t)v * 3 + 2];
+        unsigned int h = dcsg_hash3(a, b, c) & mask;
+        for (;;) {
+            unsigned int old = atomicCAS(&table[h], 0xffffffffu, v);
+            if (old == 0xffffffffu) {
+                rep[v] = v;
+                break;
+            }
+            if (vb[(size_t)old * 3] == a && vb[(size_t)old * 3 + 1] == b && vb[(size_t)old * 3 + 2] == c) {
+                rep[v] = old;
+                break;
+            }
+            h = (h + 1u) & mask;
+        }
+    }
+}
+
+// per-block count of owners (rep[v] == v) in block_sums[2*b] (second word unused: dcsg_scan_blocks scans pairs)
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_dedup_count(const unsigned int* __restrict__ rep, unsigned int n, unsigned int* __restrict__ block_sums)
+{
+    unsigned int v = blockIdx.x * DCSG_BLOCK + threadIdx.x;
+    unsigned int own = (v < n && rep[v] == v) ? 1u : 0u;
+    unsigned int w = wave_sum(own);
+    __shared__ unsigned int part[DCSG_BLOCK / DCSG_WAVE];
+    if ((threadIdx.x & (DCSG_WAVE - 1)) == 0) part[threadIdx.x / DCSG_WAVE] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int t = 0;
+        for (int k = 0; k < DCSG_BLOCK / DCSG_WAVE; k++) t += part[k];
+        block_sums[2 * blockIdx.x] = t;
+        block_sums[2 * blockIdx.x + 1] = 0;
+    }
+}
+
+// owners -> compact[slot] (positions) in buffer order; slot_of[v] = slot for owners
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_dedup_gather(const float* __restrict__ verts, const unsigned int* __restrict__ rep, unsigned int n,
+                  const unsigned int* __restrict__ block_base, float* __restrict__ compact,
+                  unsigned int* __restrict__ slot_of)
+{
+    __shared__ unsigned int wsum[DCSG_BLOCK / DCSG_WAVE];
+    unsigned int v = blockIdx.x * DCSG_BLOCK + threadIdx.x;
+    unsigned int own = (v < n && rep[v] == v) ? 1u : 0u;
+    unsigned int inc = wave_scan_incl(own);
+    const int lane = threadIdx.x & (DCSG_WAVE - 1), wave = threadIdx.x / DCSG_WAVE;
+    if (lane == DCSG_WAVE - 1) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int off = block_base[2 * blockIdx.x] + inc - own;
+    for (int k = 0; k < wave; k++) off += wsum[k];
+    if (own) {
+        slot_of[v] = off;
+        compact[(size_t)off * 3 + 0] = verts[(size_t)v * 3 + 0];
+        compact[(size_t)off * 3 + 1] = verts[(size_t)v * 3 + 1];
+        compact[(size_t)off * 3 + 2] = verts[(size_t)v * 3 + 2];
+    }
+}
+
+// every copy takes the projected position of its representative
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_dedup_scatter(float* __restrict__ verts, const unsigned int* __restrict__ rep, const unsigned int* __restrict__ slot_of,
+                   const float* __restrict__ compact, unsigned int n)
+{
+    for (unsigned int v = blockIdx.x * DCSG_BLOCK + threadIdx.x; v < n; v += gridDim.x * DCSG_BLOCK) {
+        unsigned int s = slot_of[rep[v]];
+        verts[(size_t)v * 3 + 0] = compact[(size_t)s * 3 + 0];
+        verts[(size_t)v * 3 + 1] = compact[(size_t)s * 3 + 1];
+        verts[(size_t)v * 3 + 2] = compact[(size_t)s * 3 + 2];
+    }
+}
+
 // Diagnostic: dcsg_sqrt over an array (exhaustive test of the custom square root).
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_test_sqrt(const float* __restrict__ in, float* __restrict__ out, unsigned int n)
