@@ -5,6 +5,8 @@
 // MyFrame::OnExportInner (DesignCSG.cpp:638-790).  There is no CPU fallback: without a HIP device
 // every entry point fails with DCSG_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cmath>
@@ -848,28 +850,45 @@ int dcsg_copy_triangles_device(dcsg_ctx* c, float* d_out, uint64_t max_triangles
     return 0;
 }
 
-// File images are formatted by a few host threads straight into one malloc'd buffer (no zero-fill pass) and
-// written with a single write; dcsg_export formats and writes the two files concurrently.
+// File images are produced by a few host threads, each formatting its range of triangles into a small buffer
+// and pwrite()-ing it at its final offset: formatting and the copies into the page cache run in parallel and no
+// file-sized intermediate buffer exists.  dcsg_export additionally writes the two files concurrently.
 }  // extern "C"
 
 namespace {
 
+// Runs f(t0, t1) on `nt` threads over [0, n) in equal ranges; returns false if any call returned false.
 template <class F>
-void parallel_chunks(uint64_t n, F f)
+bool parallel_ranges(uint64_t n, unsigned nt, F f)
 {
-    unsigned nt = n > (1u << 16) ? 4u : 1u;
+    if (n < (1u << 15)) nt = 1;
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
-    f(0, n / nt);
+    std::vector<char> ok(nt, 1);
+    for (unsigned t = 1; t < nt; t++) th.emplace_back([&, t] { ok[t] = f(n * t / nt, n * (t + 1) / nt) ? 1 : 0; });
+    ok[0] = f(0, n / nt) ? 1 : 0;
     for (auto& x : th) x.join();
+    for (char o : ok)
+        if (!o) return false;
+    return true;
 }
 
-int write_whole(const char* path, const unsigned char* buf, size_t bytes)
+bool pwrite_all(int fd, const unsigned char* buf, size_t bytes, off_t off)
 {
-    FILE* f = fopen(path, "wb");
-    if (!f) return DCSG_ERR_IO;
-    size_t w = fwrite(buf, 1, bytes, f);
-    return (fclose(f) == 0 && w == bytes) ? 0 : DCSG_ERR_IO;
+    while (bytes) {
+        ssize_t w = pwrite(fd, buf, bytes, off);
+        if (w <= 0) return false;
+        buf += w;
+        off += w;
+        bytes -= (size_t)w;
+    }
+    return true;
+}
+
+unsigned writer_threads()
+{
+    const char* e = getenv("DCSG_WRITER_THREADS");
+    int n = e ? atoi(e) : 4;  // per file; the two files are written concurrently
+    return n < 1 ? 1u : (n > 64 ? 64u : (unsigned)n);
 }
 
 }  // namespace
@@ -881,24 +900,30 @@ extern "C" {
 int dcsg_write_stl(const char* path, const float* tris, uint64_t n)
 {
     if (!path || (n && !tris)) return DCSG_ERR_INVALID;
-    size_t bytes = 84 + (size_t)n * 50;
-    unsigned char* buf = (unsigned char*)malloc(bytes);
-    if (!buf) return DCSG_ERR_IO;
-    memset(buf, 0, 84);
+    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return DCSG_ERR_IO;
+    unsigned char head[84];
+    memset(head, 0, sizeof(head));
     uint32_t n32 = (uint32_t)n;
-    memcpy(buf + 80, &n32, 4);
-    parallel_chunks(n, [=](uint64_t t0, uint64_t t1) {
-        unsigned char* o = buf + 84 + t0 * 50;
-        for (uint64_t t = t0; t < t1; t++, o += 50) {
-            const float* v = tris + t * 9;
-            float rec[12] = {0.0f, 0.0f, 0.0f, v[0], v[2], v[1], v[3], v[5], v[4], v[6], v[8], v[7]};
-            memcpy(o, rec, 48);
-            o[48] = o[49] = 0;
+    memcpy(head + 80, &n32, 4);
+    bool ok = pwrite_all(fd, head, sizeof(head), 0);
+    ok = ok && parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
+        const uint64_t step = 1u << 15;  // triangles per buffer (1.6 MB)
+        std::vector<unsigned char> buf((size_t)step * 50);
+        for (uint64_t a = t0; a < t1; a += step) {
+            uint64_t b = a + step < t1 ? a + step : t1;
+            unsigned char* o = buf.data();
+            for (uint64_t t = a; t < b; t++, o += 50) {
+                const float* v = tris + t * 9;
+                float rec[12] = {0.0f, 0.0f, 0.0f, v[0], v[2], v[1], v[3], v[5], v[4], v[6], v[8], v[7]};
+                memcpy(o, rec, 48);
+                o[48] = o[49] = 0;
+            }
+            if (!pwrite_all(fd, buf.data(), (size_t)(b - a) * 50, (off_t)(84 + a * 50))) return false;
         }
+        return true;
     });
-    int rc = write_whole(path, buf, bytes);
-    free(buf);
-    return rc;
+    return (close(fd) == 0 && ok) ? 0 : DCSG_ERR_IO;
 }
 
 // writeTrianglesToPLY, utils.hpp:106-154 via happly.h:1998-2039 (header), 1538-1570 (double x,y,z),
@@ -913,28 +938,32 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
                       "element vertex %llu\nproperty double x\nproperty double y\nproperty double z\n"
                       "element face %llu\nproperty list uchar uint vertex_indices\nend_header\n",
                       (unsigned long long)(n * 3), (unsigned long long)n);
-    size_t bytes = (size_t)hl + (size_t)n * (72 + 13);
-    unsigned char* buf = (unsigned char*)malloc(bytes);
-    if (!buf) return DCSG_ERR_IO;
-    memcpy(buf, header, hl);
-    unsigned char* verts = buf + hl;
-    unsigned char* faces = verts + (size_t)n * 72;
-    parallel_chunks(n, [=](uint64_t t0, uint64_t t1) {
-        unsigned char* o = verts + t0 * 72;
-        for (uint64_t i = t0 * 9; i < t1 * 9; i++, o += 8) {
-            double v = (double)tris[i];
-            memcpy(o, &v, 8);
+    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return DCSG_ERR_IO;
+    bool ok = pwrite_all(fd, (const unsigned char*)header, (size_t)hl, 0);
+    const off_t verts_at = hl, faces_at = hl + (off_t)(n * 72);
+    ok = ok && parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
+        const uint64_t step = 1u << 14;  // triangles per buffer (1.2 MB of vertices, 0.2 MB of faces)
+        std::vector<unsigned char> vbuf((size_t)step * 72), fbuf((size_t)step * 13);
+        for (uint64_t a = t0; a < t1; a += step) {
+            uint64_t b = a + step < t1 ? a + step : t1;
+            unsigned char* o = vbuf.data();
+            for (uint64_t i = a * 9; i < b * 9; i++, o += 8) {
+                double v = (double)tris[i];
+                memcpy(o, &v, 8);
+            }
+            unsigned char* q = fbuf.data();
+            for (uint64_t t = a; t < b; t++, q += 13) {
+                q[0] = 3;
+                uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
+                memcpy(q + 1, idx, 12);
+            }
+            if (!pwrite_all(fd, vbuf.data(), (size_t)(b - a) * 72, verts_at + (off_t)(a * 72))) return false;
+            if (!pwrite_all(fd, fbuf.data(), (size_t)(b - a) * 13, faces_at + (off_t)(a * 13))) return false;
         }
-        unsigned char* q = faces + t0 * 13;
-        for (uint64_t t = t0; t < t1; t++, q += 13) {
-            q[0] = 3;
-            uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
-            memcpy(q + 1, idx, 12);
-        }
+        return true;
     });
-    int rc = write_whole(path, buf, bytes);
-    free(buf);
-    return rc;
+    return (close(fd) == 0 && ok) ? 0 : DCSG_ERR_IO;
 }
 
 int dcsg_debug_sqrt_device(dcsg_ctx* c, const float* d_in, size_t n, float* d_out, void* stream)
