@@ -5,10 +5,13 @@ Metric (BASELINE.json): Mvoxels/s of SDF+normal evaluation.  A step is one sweep
 (res+1)^3 lattice of the workload into buffers resident in HBM; voxels = res^3.  Default workload
 is BASELINE config 2 (single sphere, 512^3, box from the reference's own stage-A estimate).
 
-N > 1 (one process per GPU, torch.distributed over RCCL): the fixed lattice is sharded into N
-Z slabs; each rank sweeps its planes and receives the one halo plane its mesher
-needs from its upper neighbour over RCCL send/recv (the only exchange the path has).  Total work
-is fixed, so scaling is "strong".
+N > 1 (one process per GPU, torch.distributed over RCCL), default `--scaling weak`: the domain is N
+lattice boxes of the workload's size stacked along z (rank r's box is the workload's box shifted by
+r diameters), i.e. one long lattice cut into N Z slabs of (res+1)^2 x res points; every rank sweeps its
+slab and receives the boundary plane it shares with its upper neighbour over RCCL send/recv -- the one
+plane a slab's mesher needs beyond its own, and the only exchange the path has.
+Per-GPU work is fixed, value = N * res^3 voxels / time.  `--scaling strong` shards the single
+workload lattice into N thinner Z slabs instead (total work fixed).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -113,6 +116,9 @@ def main():
     ap.add_argument("--workload", default="sphere512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-halo", action="store_true", help="after the timed loop, check the received halo plane")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = one workload-sized lattice box per rank, stacked along z (default); "
+                         "strong = the single workload lattice split into N Z slabs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default, what the driver runs); gloo = rehearsal of the N>1 logic on "
                          "a box with fewer GPUs than ranks: halo planes are staged through host memory")
@@ -147,10 +153,17 @@ def main():
     if status != 0:
         sys.exit("scene build failed:\n" + log)
 
-    # Z slab of this rank: planes [lo, hi) are its own, plane hi is the halo its mesher reads;
-    # the last rank owns plane res as well.
-    lo, hi = rank * res // world, (rank + 1) * res // world
-    own_hi = hi if rank < world - 1 else n1
+    # Z slab of this rank: planes [lo, hi) are its own, plane hi is the halo its mesher reads (the upper
+    # neighbour's first plane); the last rank owns plane hi as well.
+    weak = args.scaling == "weak" or world == 1
+    if weak:
+        lo, hi = 0, res                                   # a whole box per rank ...
+        center = [center[0], center[1], center[2] + rank * diameter]   # ... stacked along z
+        total_voxels = world * res ** 3
+    else:
+        lo, hi = rank * res // world, (rank + 1) * res // world
+        total_voxels = res ** 3
+    own_hi = hi if rank < world - 1 else hi + 1
     planes = hi - lo + 1
     plane = n1 * n1
     sdf = torch.empty(planes * plane, dtype=torch.float32, device="cuda")
@@ -244,18 +257,20 @@ def main():
         workload = ("%s scene, fused SDF+normal sweep of the %d^3 lattice (%d^3 voxels), box centre %s diameter %s"
                     % (scene, n1, res, center, diameter))
         ms_per_step = dt / args.steps * 1e3
-        value = res ** 3 * args.steps / dt / 1e6
+        value = total_voxels * args.steps / dt / 1e6
         kernel_ms = sum(a.elapsed_time(b) for a, b in k_ev) / args.steps
         own_points = (own_hi - lo) * plane
         achieved = BYTES_PER_POINT * own_points / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "Mvoxels/s SDF+normal eval", "value": round(value, 2), "unit": "Mvoxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload,
-                       "grid_level": grid_level, "parallelism": "z-slab x%d" % world,
-                       "lattice_points": n1 ** 3},
+                       "grid_level": grid_level,
+                       "parallelism": ("z-slab x%d: %d stacked %d^3-voxel boxes, boundary plane over RCCL" % (world, world, res)
+                                       if weak else "z-slab x%d of one %d^3-voxel lattice, halo plane over RCCL" % (world, res)),
+                       "lattice_points": (world * res + 1) * plane if weak else n1 ** 3},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
