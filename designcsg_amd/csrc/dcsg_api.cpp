@@ -465,6 +465,11 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
         c->jit = true;
     }
     c->specialised = c->jit && plan.specialise;
+    // every kernel stages the scene tables in LDS: they must fit one workgroup's share (160 KiB on gfx950)
+    if (s.lds_bytes() > 160 * 1024)
+        return fail(c, DCSG_ERR_INVALID,
+                    "scene tables need " + std::to_string(s.lds_bytes()) + " B of LDS (" + std::to_string(s.n_objects) +
+                        " objects, " + std::to_string(s.n_steps) + " build steps); the limit is 163840 B (about 1400 objects)");
     int r = ensure(c, c->d_blob, s.blob.size() * 4);
     if (r) return r;
     HIPCHK(c, hipMemcpy(c->d_blob.p, s.blob.data(), s.blob.size() * 4, hipMemcpyHostToDevice));

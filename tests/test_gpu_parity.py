@@ -316,3 +316,36 @@ def test_set_arbitrary_data_after_build(ev, oracle):
     osc = oracle.Scene(s["scene.txt"], s["buildprocedure.txt"], scene_dir("ad_table") + "/scene.cl", table)
     assert not np.array_equal(a, b)
     assert np.array_equal(bits(b), bits(osc.eval_sdf(pts)))
+
+
+def test_large_object_tables(built_lib, oracle):
+    """Beyond the reference's MAX_OBJECTS 512 / MAX_BUILD_STEPS 256 (DrawPane.h:14-15): the tables live in LDS, so
+    ~1400 objects fit (160 KiB); more is refused with a clear error instead of overflowing."""
+    from designcsg_amd import _lib
+    from designcsg_amd.evaluator import Evaluator
+    rng = np.random.default_rng(0)
+
+    def scene(n):
+        rows, bp = ["0 1 0 0 0 0.2 0 0 0 0.2 0 0 0 0.2"], ["0 0 0 0"]
+        for i in range(n):
+            p, s = rng.uniform(-4, 4, 3), 1.0 / rng.uniform(0.2, 0.6)
+            rows.append("2 1 %.6f %.6f %.6f %.6f 0 0 0 %.6f 0 0 0 %.6f" % (p[0], p[1], p[2], s, s, s))
+            bp += ["0 2 %d 1" % (i + 1), "2 0 1 0"]
+        return "\n".join(rows) + "\n", "\n".join(bp + ["1 0 -1 -1"])
+
+    e = Evaluator(0)
+    try:
+        st, bp = scene(1200)
+        assert e.build(st, bp, None)[0] == 0
+        pts = rng.uniform(-5, 5, (4000, 3)).astype(np.float32)
+        osc = oracle.Scene(st, bp)
+        assert np.array_equal(bits(e.eval_sdf_at_points(pts)), bits(osc.eval_sdf(pts)))
+        gs, gn = e.eval_lattice([0.0, 0.0, 0.0], 10.0, 16)
+        ws, wn = osc.eval_lattice([0.0, 0.0, 0.0], 10.0, 16)
+        assert np.array_equal(bits(gs), bits(ws)) and np.array_equal(bits(gn), bits(wn))
+        st, bp = scene(2400)
+        with pytest.raises(_lib.DcsgError) as ei:
+            e.build(st, bp, None)
+        assert ei.value.code == _lib.ERR_INVALID and "LDS" in ei.value.message
+    finally:
+        e.close()
