@@ -564,6 +564,15 @@ __device__ __forceinline__ DcsgClamp2 dcsg_clamp_wave_scan(DcsgClamp2 v)
     return v;
 }
 
+// keep test of a step given the interval [lo, hi] of the accumulator before it
+__device__ __forceinline__ bool dcsg_step_keep(int op, float lb, float ub, float lo, float hi)
+{
+    if (op == SOP_ACC_MIN) return !(lb > hi);    // T_min(a, s) = a wherever a < s
+    if (op == SOP_ACC_MAX) return !(ub < lo);    // T_max(a, s) = a wherever a > s
+    if (op == SOP_ACC_NEGMAX) return !(-lb < lo);
+    return op >= 0;                              // PUSH, POP, EXPORT: always
+}
+
 // value of one PUSH / ACC step at the tile centre with its margin: s in [lb, ub] over the tile
 __device__ __forceinline__ void dcsg_step_bounds(const SceneLds& s, const int4& st, float cx, float cy, float cz, float R,
                                                  float& lb, float& ub)
@@ -587,12 +596,17 @@ __device__ __forceinline__ void dcsg_step_bounds(const SceneLds& s, const int4& 
 // accumulator's interval.  A leaf is one accumulate step; a group "PUSH, ACC..., POP_x" is walked step by step
 // (interval arithmetic on its own accumulator) and then acts like an accumulate of its result with the POP's
 // operator.  op = -1 for "no item"; first/count = the item's steps.
+// mask: bit j set = step first+j of the item has to run.  Inside a group a leaf whose bound strictly decides its
+// comparison against the GROUP's accumulator interval cannot change that accumulator anywhere in the tile and
+// is dropped (groups longer than 64 steps keep all their steps).
 __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, float cx, float cy, float cz, float R, int& op,
-                                                      float& lb, float& ub, int& first, int& count)
+                                                      float& lb, float& ub, int& first, int& count,
+                                                      unsigned long long& mask)
 {
     op = -1;
     lb = ub = 0.0f;
     first = count = 0;
+    mask = 1ull;
     DcsgClamp2 k = dcsg_clamp_identity();
     if (i >= s.n_items) return k;
     int4 it = s.items[i];
@@ -605,10 +619,14 @@ __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, 
         dcsg_step_bounds(s, s.stack_steps[first], cx, cy, cz, R, lb, ub);
     } else {
         float glo = 0.0f, ghi = 0.0f;
+        const bool small = count <= 64;
+        mask = small ? (1ull << (count - 1)) : ~0ull;  // the POP always runs
         for (int j = 0; j < count - 1; j++) {
             int4 st = s.stack_steps[first + j];
             float b0, b1;
             dcsg_step_bounds(s, st, cx, cy, cz, R, b0, b1);
+            bool keep = dcsg_step_keep(st.x, b0, b1, glo, ghi);
+            if (keep && small) mask |= 1ull << j;
             if (st.x == SOP_PUSH) {
                 glo = b0;
                 ghi = b1;
@@ -634,15 +652,6 @@ __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, 
     return k;
 }
 
-// keep test of a step given the interval [lo, hi] of the accumulator before it
-__device__ __forceinline__ bool dcsg_step_keep(int op, float lb, float ub, float lo, float hi)
-{
-    if (op == SOP_ACC_MIN) return !(lb > hi);    // T_min(a, s) = a wherever a < s
-    if (op == SOP_ACC_MAX) return !(ub < lo);    // T_max(a, s) = a wherever a > s
-    if (op == SOP_ACC_NEGMAX) return !(-lb < lo);
-    return op >= 0;                              // PUSH, POP, EXPORT: always
-}
-
 // Builds the wave's active-step list for the tile that contains the valid lanes' points (x,y,z); `pad` is
 // added to every half extent (the stencil's epsilon).  Returns the number of steps kept (wave-uniform).
 __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool valid, float x, float y, float z, float pad,
@@ -662,7 +671,8 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
     for (int base = 0; base < n; base += DCSG_WAVE) {
         int op, first, count;
         float lb, ub;
-        DcsgClamp2 mine = dcsg_item_clamp(s, base + lane, cx, cy, cz, R, op, lb, ub, first, count);
+        unsigned long long imask;
+        DcsgClamp2 mine = dcsg_item_clamp(s, base + lane, cx, cy, cz, R, op, lb, ub, first, count, imask);
         DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
         DcsgClamp2 excl = dcsg_clamp_shfl_up(incl, 1);
         if (lane == 0) excl = dcsg_clamp_identity();
@@ -670,10 +680,18 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
         // a program starts with PUSH, so the clamp before any accumulate is constant: apply it to 0
         float lo = fminf(fmaxf(0.0f, before.plo), before.qlo), hi = fminf(fmaxf(0.0f, before.phi), before.qhi);
         bool keep = dcsg_step_keep(op, lb, ub, lo, hi);
-        unsigned int sz = keep ? (unsigned int)count : 0u;
+        const bool all_steps = count > 64;
+        unsigned int sz = keep ? (all_steps ? (unsigned int)count : (unsigned int)__popcll(imask)) : 0u;
         unsigned int inc = wave_scan_incl(sz);
         unsigned int off = (unsigned int)n_active + inc - sz;
-        for (unsigned int j = 0; j < sz; j++) list[off + j] = (unsigned short)(first + (int)j);
+        if (keep) {
+            if (all_steps) {
+                for (int j = 0; j < count; j++) list[off + j] = (unsigned short)(first + j);
+            } else {
+                unsigned int w = off;
+                for (unsigned long long m = imask; m; m &= m - 1ull) list[w++] = (unsigned short)(first + __builtin_ctzll(m));
+            }
+        }
         n_active += (int)__shfl(inc, DCSG_WAVE - 1, DCSG_WAVE);
         DcsgClamp2 last = {__shfl(incl.plo, DCSG_WAVE - 1, DCSG_WAVE), __shfl(incl.qlo, DCSG_WAVE - 1, DCSG_WAVE),
                            __shfl(incl.phi, DCSG_WAVE - 1, DCSG_WAVE), __shfl(incl.qhi, DCSG_WAVE - 1, DCSG_WAVE)};
@@ -1377,7 +1395,8 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
     for (int base = 0; base < n; base += DCSG_BLOCK) {
         int op, first, count;
         float lb, ub;
-        DcsgClamp2 mine = dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count);
+        unsigned long long imask;
+        DcsgClamp2 mine = dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask);
         DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
         if (lane == DCSG_WAVE - 1) {
             wtot[4 * wave + 0] = incl.plo;
@@ -1394,7 +1413,8 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
         DcsgClamp2 before = dcsg_clamp_compose(pre, excl);
         float lo = fminf(fmaxf(0.0f, before.plo), before.qlo), hi = fminf(fmaxf(0.0f, before.phi), before.qhi);
         bool keep = dcsg_step_keep(op, lb, ub, lo, hi);
-        unsigned int sz = keep ? (unsigned int)count : 0u;
+        const bool all_steps = count > 64;
+        unsigned int sz = keep ? (all_steps ? (unsigned int)count : (unsigned int)__popcll(imask)) : 0u;
         unsigned int inc = wave_scan_incl(sz);
         if (lane == DCSG_WAVE - 1) wcnt[wave] = (int)inc;
         for (int w = 0; w < DCSG_BLOCK / DCSG_WAVE; w++)
@@ -1402,7 +1422,14 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
         __syncthreads();
         unsigned int off = (unsigned int)n_active + inc - sz;
         for (int w = 0; w < wave; w++) off += (unsigned int)wcnt[w];
-        for (unsigned int j = 0; j < sz; j++) list[off + j] = (unsigned short)(first + (int)j);
+        if (keep) {
+            if (all_steps) {
+                for (int j = 0; j < count; j++) list[off + j] = (unsigned short)(first + j);
+            } else {
+                unsigned int wpos = off;
+                for (unsigned long long m = imask; m; m &= m - 1ull) list[wpos++] = (unsigned short)(first + __builtin_ctzll(m));
+            }
+        }
         for (int w = 0; w < DCSG_BLOCK / DCSG_WAVE; w++) n_active += wcnt[w];
         __syncthreads();  // list entries visible; wtot / wcnt free for the next chunk
     }
