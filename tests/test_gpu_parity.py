@@ -118,6 +118,16 @@ def test_lattice_sweep_bit_exact(ev, oracle, name):
     gs2, gn2 = ev.eval_lattice(center, diameter[0], 64, z0=17, z1=40)
     assert np.array_equal(bits(gs2), bits(ws[17:40]))
     assert np.array_equal(bits(gn2), bits(wn[17:40]))
+    # SDF-only sweeps (what the export runs when normals are sampled on demand)
+    gs3, _ = ev.eval_lattice(center, diameter[0], 64, normals=False)
+    assert np.array_equal(bits(gs3), bits(ws))
+    gs4, _ = ev.eval_lattice(center, diameter[0], 64, z0=17, z1=40, normals=False)
+    assert np.array_equal(bits(gs4), bits(ws[17:40]))
+    gs5, _ = ev.eval_lattice(center, diameter[0], 64, z0=3, z1=8, normals=False)
+    assert np.array_equal(bits(gs5), bits(ws[3:8]))
+    for r in (1, 4, 7, 8):   # tiny lattices
+        gs6, _ = ev.eval_lattice(center, diameter[0], r, normals=False)
+        assert np.array_equal(bits(gs6), bits(osc.eval_lattice(center, diameter[0], r, normals=False)[0]))
 
 
 GOLD_BBOX = {  # centre, diameter, interior points
