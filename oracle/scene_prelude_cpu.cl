@@ -59,6 +59,22 @@ float  DCSG_OVL clamp(float x, float lo, float hi){ return min(max(x,lo),hi); }
 uint   DCSG_OVL abs(int a){ return (uint)(a < 0 ? -a : a); }
 float  DCSG_OVL floor(float x){ return __builtin_floorf(x); }
 float  DCSG_OVL ceil(float x){ return __builtin_ceilf(x); }
+float  DCSG_OVL trunc(float x){ return __builtin_truncf(x); }
+float2 DCSG_OVL max(float2 a, float2 b){ return (float2)(max(a.x,b.x),max(a.y,b.y)); }
+float2 DCSG_OVL min(float2 a, float2 b){ return (float2)(min(a.x,b.x),min(a.y,b.y)); }
+float2 DCSG_OVL max(float2 a, float b){ return (float2)(max(a.x,b),max(a.y,b)); }
+float2 DCSG_OVL min(float2 a, float b){ return (float2)(min(a.x,b),min(a.y,b)); }
+float2 DCSG_OVL clamp(float2 x, float lo, float hi){ return min(max(x,lo),hi); }
+float3 DCSG_OVL clamp(float3 x, float lo, float hi){ return min(max(x,lo),hi); }
+float3 DCSG_OVL clamp(float3 x, float3 lo, float3 hi){ return min(max(x,lo),hi); }
+int    DCSG_OVL clamp(int x, int lo, int hi){ return min(max(x,lo),hi); }
+float  DCSG_OVL mix(float x, float y, float a){ return x+(y-x)*a; }
+float3 DCSG_OVL mix(float3 x, float3 y, float a){ return (float3)(mix(x.x,y.x,a),mix(x.y,y.y,a),mix(x.z,y.z,a)); }
+float  DCSG_OVL step(float edge, float x){ return x < edge ? 0.0f : 1.0f; }
+float  DCSG_OVL sign(float x){ return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : (x == 0.0f ? x : 0.0f)); }
+float  DCSG_OVL mad(float a, float b, float c){ return a*b+c; }
+float  DCSG_OVL distance(float2 a, float2 b){ return length(a-b); }
+float3 DCSG_OVL cross(float3 a, float3 b){ return (float3)(a.y*b.z-a.z*b.y, a.z*b.x-a.x*b.z, a.x*b.y-a.y*b.x); }
 /* unpinned (libm on the host, ocml on the device): */
 float  DCSG_OVL sin(float x){ return __builtin_sinf(x); }
 float  DCSG_OVL cos(float x){ return __builtin_cosf(x); }

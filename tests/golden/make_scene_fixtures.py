@@ -39,6 +39,7 @@ DESIGNS = {
     "grouped256": os.path.join(OWN_DESIGNS, "grouped256.py"),
     "ad_table": os.path.join(OWN_DESIGNS, "ad_table.py"),
     "prefabs": os.path.join(OWN_DESIGNS, "prefabs.py"),
+    "const_table": os.path.join(OWN_DESIGNS, "const_table.py"),
 }
 FILES = ["scene.txt", "buildprocedure.txt", "scene.cl", "exportConfig.txt"]
 

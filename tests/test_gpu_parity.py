@@ -11,7 +11,7 @@ from conftest import export_config_text, read_scene, scene_dir
 
 pytestmark = pytest.mark.gpu
 
-ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table", "prefabs"]
+ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table", "prefabs", "const_table"]
 STL_TOL = 1e-5  # north_star: ".stl diff within 1e-5"
 
 
@@ -41,10 +41,10 @@ def sorted_tris(t):
 
 
 EXPECTED_STACK_DEPTH = {"sphere": 1, "design1": 1, "design2": 1, "flat256": 1, "mixed_groups": 2, "grouped256": 2,
-                        "ad_table": 1, "prefabs": 2}
+                        "ad_table": 1, "prefabs": 2, "const_table": 1}
 
 
-SPECIALISED = {"sphere", "design1", "design2", "mixed_groups", "ad_table", "prefabs"}  # <= 48 object evaluations
+SPECIALISED = {"sphere", "design1", "design2", "mixed_groups", "ad_table", "prefabs", "const_table"}  # <= 48 object evaluations
 
 
 @pytest.mark.parametrize("interpreter", ["auto", "stack", "generic"])
@@ -94,7 +94,7 @@ def test_builtin_bank_equals_jit_bank(ev, oracle):
     assert np.array_equal(bits(a), bits(b))
 
 
-@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table", "flat256", "grouped256"])
+@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table", "const_table", "flat256", "grouped256"])
 def test_lattice_sweep_bit_exact(ev, oracle, name):
     load(ev, name)
     osc = oracle.Scene.from_dir(scene_dir(name))
@@ -154,7 +154,7 @@ GOLD_TRIS_128 = {  # levels 4/6/7, per-level triangle counts
 }
 
 
-@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups", "ad_table"])
+@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups", "ad_table", "const_table"])
 @pytest.mark.parametrize("dense_normals", [False, True])
 def test_mesher_and_projection_bit_exact(ev, oracle, lookup_table, name, dense_normals, tmp_path):
     load(ev, name)
