@@ -38,6 +38,8 @@ WORKLOADS = {
     "flat256_512": ("flat256", 9, [0.0, 0.0, 0.0], 10.0),
     "flat256_1024": ("flat256", 10, [0.0, 0.0, 0.0], 10.0),
     "grouped256_512": ("grouped256", 9, [0.0, 0.0, 0.0], 10.0),
+    "smooth256_512": ("smooth256", 9, [0.0, 0.0, 0.0], 10.0),     # smooth-join extension (no culling)
+    "smooth256_1024": ("smooth256", 10, [0.0, 0.0, 0.0], 10.0),
 }
 
 

@@ -217,7 +217,7 @@ bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std:
     }
     // Small stack-disciplined programs are specialised: the whole evaluation becomes straight-line code.
     int n_evals = 0;
-    for (int k = 0; k < s.n_stack_prog; k++) n_evals += s.stack_prog[4 * k] <= 35 ? 1 : 0;
+    for (int k = 0; k < s.n_stack_prog; k++) n_evals += (s.stack_prog[4 * k] <= 35 || (s.stack_prog[4 * k] >= 41 && s.stack_prog[4 * k] <= 43)) ? 1 : 0;
     const char* env_spec = getenv("DCSG_SPECIALISE");  // max object evaluations to specialise; 0 disables
     int spec_limit = env_spec ? atoi(env_spec) : 48;
     p.specialise = s.n_stack_prog > 0 && n_evals <= spec_limit;
@@ -480,7 +480,7 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     // groups), enough objects to pay off.
     {
         int n_evals = 0;
-        for (int k = 0; k < c->scene.n_stack_prog; k++) n_evals += c->scene.stack_prog[4 * k] <= 35 ? 1 : 0;
+        for (int k = 0; k < c->scene.n_stack_prog; k++) n_evals += (c->scene.stack_prog[4 * k] <= 35 || (c->scene.stack_prog[4 * k] >= 41 && c->scene.stack_prog[4 * k] <= 43)) ? 1 : 0;
         const char* env_cull = getenv("DCSG_CULL");
         int min_objects = env_cull ? atoi(env_cull) : 16;  // 0 disables
         if (!c->jit && c->scene.n_items > 0 && min_objects > 0 && n_evals >= min_objects) c->variant = 4;

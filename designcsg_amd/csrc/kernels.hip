@@ -36,6 +36,11 @@
 #define OP_MAX 3
 #define OP_NEGATE 4
 #define OP_IDENTITY 5
+// Extension opcodes (not in the reference; DESIGN.md section 11, oracle/dcsg_oracle.c OP_SMOOTH_*): smooth joins
+// with the blend radius loaded by SET_K {k bits, bits of 1.0f/k}.
+#define OP_SMOOTH_MIN 6
+#define OP_SMOOTH_MAX 7
+#define OP_SET_K 8
 
 // ---------------------------------------------------------------------------
 // Correctly rounded sqrtf.  v_sqrt_f32 is good to 1 ulp; the IEEE result is obtained by testing the two
@@ -202,6 +207,26 @@ __device__ __forceinline__ SceneLds dcsg_stage_scene(const uint4* __restrict__ b
 #define OP_IMPORT_MIN 16     // stack[dest] = T_min(stack[dest], sdf)
 #define OP_IMPORT_MAX 17     // stack[dest] = T_max(stack[dest], sdf)
 #define OP_IMPORT_NEGMAX 18  // stack[dest] = T_max(stack[dest], -sdf)
+#define OP_IMPORT_SMIN 19    // the same three with the smooth joins
+#define OP_IMPORT_SMAX 20
+#define OP_IMPORT_NEGSMAX 21
+
+// Polynomial smooth minimum / maximum with blend radius k (extension, see OP_SMOOTH_MIN): float, left to right.
+__device__ __forceinline__ float dcsg_smooth_term(float a, float b, float k, float inv_k)
+{
+    float t = k - __builtin_fabsf(a - b);
+    t = t > 0.0f ? t : 0.0f;
+    float h = t * inv_k;
+    return ((h * h) * k) * 0.25f;
+}
+__device__ __forceinline__ float dcsg_smin(float a, float b, float k, float inv_k)
+{
+    return (a < b ? a : b) - dcsg_smooth_term(a, b, k, inv_k);
+}
+__device__ __forceinline__ float dcsg_smax(float a, float b, float k, float inv_k)
+{
+    return (a > b ? a : b) + dcsg_smooth_term(a, b, k, inv_k);
+}
 
 // ---------------------------------------------------------------------------
 // Generic interpreter: one point, stack in LDS (any slot count up to 64).
@@ -227,6 +252,7 @@ __device__ __forceinline__ float dcsg_import(const SceneLds& s, int shape, int o
 __device__ __forceinline__ float dcsg_primary_sdf(const SceneLds& s, float x, float y, float z)
 {
     float export_value = (float)K2_MAX_DISTANCE;
+    float k = 0.0f, inv_k = 0.0f;  // blend radius of the smooth joins (wave-uniform)
     for (int c = 0; c < s.n_steps; c++) {
         int4 st = s.steps[c];
         int op = __builtin_amdgcn_readfirstlane(st.x);
@@ -258,6 +284,25 @@ __device__ __forceinline__ float dcsg_primary_sdf(const SceneLds& s, float x, fl
         } break;
         case OP_NEGATE: s.stack[dest * DCSG_BLOCK] = -s.stack[left * DCSG_BLOCK]; break;
         case OP_IDENTITY: s.stack[dest * DCSG_BLOCK] = s.stack[left * DCSG_BLOCK]; break;
+        case OP_SET_K:
+            k = __int_as_float(left);
+            inv_k = __int_as_float(right);
+            break;
+        case OP_SMOOTH_MIN:
+            s.stack[dest * DCSG_BLOCK] = dcsg_smin(s.stack[left * DCSG_BLOCK], s.stack[right * DCSG_BLOCK], k, inv_k);
+            break;
+        case OP_SMOOTH_MAX:
+            s.stack[dest * DCSG_BLOCK] = dcsg_smax(s.stack[left * DCSG_BLOCK], s.stack[right * DCSG_BLOCK], k, inv_k);
+            break;
+        case OP_IMPORT_SMIN:
+            s.stack[dest * DCSG_BLOCK] = dcsg_smin(s.stack[dest * DCSG_BLOCK], dcsg_import(s, left & 0xff, right, x, y, z), k, inv_k);
+            break;
+        case OP_IMPORT_SMAX:
+            s.stack[dest * DCSG_BLOCK] = dcsg_smax(s.stack[dest * DCSG_BLOCK], dcsg_import(s, left & 0xff, right, x, y, z), k, inv_k);
+            break;
+        case OP_IMPORT_NEGSMAX:
+            s.stack[dest * DCSG_BLOCK] = dcsg_smax(s.stack[dest * DCSG_BLOCK], -dcsg_import(s, left & 0xff, right, x, y, z), k, inv_k);
+            break;
         default: break;
         }
     }
@@ -373,6 +418,13 @@ __device__ __forceinline__ void dcsg_bank_n(const float (&A)[N], const float (&B
 #define SOP_POP_MAX 37
 #define SOP_POP_NEGMAX 38
 #define SOP_EXPORT_TOP 39
+#define SOP_SET_K 40        // extension (smooth joins): k = as_float(left), 1/k = as_float(right)
+#define SOP_ACC_SMIN 41
+#define SOP_ACC_SMAX 42
+#define SOP_ACC_NEGSMAX 43
+#define SOP_POP_SMIN 44
+#define SOP_POP_SMAX 45
+#define SOP_POP_NEGSMAX 46
 
 // `list` (LDS, wave-uniform contents) optionally restricts the pass to a subset of the steps, in program
 // order: the active-step list of the tile culling below.
@@ -388,6 +440,7 @@ __device__ __forceinline__ void dcsg_interp(const SceneLds& s, const float (&px)
         for (int k = 0; k < N; k++) stk[i][k] = 0.0f;
 #pragma unroll
     for (int k = 0; k < N; k++) out[k] = (float)K2_MAX_DISTANCE;
+    float bk = 0.0f, inv_bk = 0.0f;  // blend radius of the smooth joins (wave-uniform)
     const int n_run = list ? n_list : s.n_stack_steps;
     for (int k_run = 0; k_run < n_run; k_run++) {
         const int c = list ? __builtin_amdgcn_readfirstlane((int)list[k_run]) : k_run;
@@ -396,7 +449,7 @@ __device__ __forceinline__ void dcsg_interp(const SceneLds& s, const float (&px)
         int left = __builtin_amdgcn_readfirstlane(st.y);
         int right = __builtin_amdgcn_readfirstlane(st.z);
         int depth = __builtin_amdgcn_readfirstlane(st.w);
-        if (op <= SOP_ACC_NEGMAX) {  // PUSH / ACC_*: evaluate the object at the N points
+        if (op <= SOP_ACC_NEGMAX || (op >= SOP_ACC_SMIN && op <= SOP_ACC_NEGSMAX)) {  // PUSH / ACC_*: evaluate the object at the N points
             float r[N];
             int shape = left & 0xff;
             if (shape == 0 && (s.flags & 1)) {
@@ -433,23 +486,34 @@ __device__ __forceinline__ void dcsg_interp(const SceneLds& s, const float (&px)
             } else if (op == SOP_ACC_MAX) {
 #pragma unroll
                 for (int k = 0; k < N; k++) stk[0][k] = stk[0][k] > r[k] ? stk[0][k] : r[k];
-            } else {
+            } else if (op == SOP_ACC_NEGMAX) {
 #pragma unroll
                 for (int k = 0; k < N; k++) {
                     float nb = -r[k];
                     stk[0][k] = stk[0][k] > nb ? stk[0][k] : nb;
                 }
+            } else if (op == SOP_ACC_SMIN) {
+#pragma unroll
+                for (int k = 0; k < N; k++) stk[0][k] = dcsg_smin(stk[0][k], r[k], bk, inv_bk);
+            } else if (op == SOP_ACC_SMAX) {
+#pragma unroll
+                for (int k = 0; k < N; k++) stk[0][k] = dcsg_smax(stk[0][k], r[k], bk, inv_bk);
+            } else {
+#pragma unroll
+                for (int k = 0; k < N; k++) stk[0][k] = dcsg_smax(stk[0][k], -r[k], bk, inv_bk);
             }
-        } else if (op <= SOP_POP_NEGMAX) {  // join the top group into its parent (stk[1])
+        } else if (op <= SOP_POP_NEGMAX || (op >= SOP_POP_SMIN && op <= SOP_POP_NEGSMAX)) {  // join the top group into its parent (stk[1])
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 float a = stk[1][k], b = stk[0][k];
                 if (op == SOP_POP_MIN) stk[0][k] = a < b ? a : b;
                 else if (op == SOP_POP_MAX) stk[0][k] = a > b ? a : b;
-                else {
+                else if (op == SOP_POP_NEGMAX) {
                     float nb = -b;
                     stk[0][k] = a > nb ? a : nb;
-                }
+                } else if (op == SOP_POP_SMIN) stk[0][k] = dcsg_smin(a, b, bk, inv_bk);
+                else if (op == SOP_POP_SMAX) stk[0][k] = dcsg_smax(a, b, bk, inv_bk);
+                else stk[0][k] = dcsg_smax(a, -b, bk, inv_bk);
             }
 #pragma unroll
             for (int lvl = 1; lvl <= D - 2; lvl++) {
@@ -461,6 +525,9 @@ __device__ __forceinline__ void dcsg_interp(const SceneLds& s, const float (&px)
         } else if (op == SOP_EXPORT_TOP) {
 #pragma unroll
             for (int k = 0; k < N; k++) out[k] = stk[0][k];
+        } else if (op == SOP_SET_K) {
+            bk = __int_as_float(left);
+            inv_bk = __int_as_float(right);
         }
     }
 }

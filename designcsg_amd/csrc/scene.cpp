@@ -87,6 +87,7 @@ bool parse_scene(const char* scene_txt, const char* bp_txt, Scene& s, std::strin
         if (a > max_slot) max_slot = a;
         return true;
     };
+    bool have_k = false;
     for (int c = 0; c < s.n_steps; c++) {
         int op = s.steps[4 * c], l = s.steps[4 * c + 1], r = s.steps[4 * c + 2], d = s.steps[4 * c + 3];
         switch (op) {
@@ -110,6 +111,25 @@ bool parse_scene(const char* scene_txt, const char* bp_txt, Scene& s, std::strin
         case 5:  // NEGATE / IDENTITY l -> d
             if (!slot_ok(l, "source", c) || !slot_ok(d, "destination", c)) return false;
             break;
+        case 6:
+        case 7:  // extension: SMOOTH_MIN / SMOOTH_MAX l r -> d  (blend radius from the last SET_K)
+            if (!slot_ok(l, "left", c) || !slot_ok(r, "right", c) || !slot_ok(d, "destination", c)) return false;
+            if (!have_k) {
+                err = "buildprocedure.txt: step " + std::to_string(c) + " is a smooth join but no SET_K step precedes it";
+                return false;
+            }
+            s.has_smooth = true;
+            break;
+        case 8: {  // extension: SET_K bits(l)
+            float k;
+            int32_t bits = l;
+            memcpy(&k, &bits, 4);
+            if (!(k > 0.0f) || k - k != 0.0f) {
+                err = "buildprocedure.txt: step " + std::to_string(c) + " sets a blend radius that is not finite and > 0";
+                return false;
+            }
+            have_k = true;
+        } break;
         default:  // k2.cl's switch ignores unknown opcodes; so do the kernels
             break;
         }
@@ -131,8 +151,25 @@ size_t Scene::lds_bytes() const
 namespace {
 struct Step {
     int op, l, r, d;
+    uint32_t k = 0;  // blend radius (float bits) of a smooth join, else 0
 };
-enum { IMPORT = 0, EXPORT = 1, MIN = 2, MAX = 3, NEGATE = 4, IDENTITY = 5, IMPORT_MIN = 16, IMPORT_MAX = 17, IMPORT_NEGMAX = 18 };
+enum {
+    IMPORT = 0, EXPORT = 1, MIN = 2, MAX = 3, NEGATE = 4, IDENTITY = 5,
+    SMIN = 6, SMAX = 7, SETK = 8,  // extension opcodes of the file format (smooth joins)
+    IMPORT_MIN = 16, IMPORT_MAX = 17, IMPORT_NEGMAX = 18, IMPORT_SMIN = 19, IMPORT_SMAX = 20, IMPORT_NEGSMAX = 21
+};
+
+// {op, k bits, bits of 1.0f/k, 0}: the step that loads the blend radius before a smooth join whose radius differs
+// from the one in force
+void push_setk(std::vector<int32_t>& prog, int op, uint32_t kbits)
+{
+    float k, inv;
+    memcpy(&k, &kbits, 4);
+    inv = 1.0f / k;
+    uint32_t ib;
+    memcpy(&ib, &inv, 4);
+    prog.insert(prog.end(), {op, (int32_t)kbits, (int32_t)ib, 0});
+}
 
 // slots a step reads / the slot it writes (-1: none)
 void step_access(const Step& t, int reads[2], int& write)
@@ -142,10 +179,15 @@ void step_access(const Step& t, int reads[2], int& write)
     case IMPORT: write = t.d; break;
     case IMPORT_MIN:
     case IMPORT_MAX:
-    case IMPORT_NEGMAX: reads[0] = t.d; write = t.d; break;
+    case IMPORT_NEGMAX:
+    case IMPORT_SMIN:
+    case IMPORT_SMAX:
+    case IMPORT_NEGSMAX: reads[0] = t.d; write = t.d; break;
     case EXPORT: reads[0] = t.l; break;
     case MIN:
-    case MAX: reads[0] = t.l; reads[1] = t.r; write = t.d; break;
+    case MAX:
+    case SMIN:
+    case SMAX: reads[0] = t.l; reads[1] = t.r; write = t.d; break;
     case NEGATE:
     case IDENTITY: reads[0] = t.l; write = t.d; break;
     default: break;
@@ -168,7 +210,18 @@ bool dead_after(const std::vector<Step>& p, size_t j, int R)
 void optimise_program(Scene& s)
 {
     std::vector<Step> in, out;
-    for (int c = 0; c < s.n_steps; c++) in.push_back({s.steps[4 * c], s.steps[4 * c + 1], s.steps[4 * c + 2], s.steps[4 * c + 3]});
+    {
+        uint32_t cur_k = 0;
+        for (int c = 0; c < s.n_steps; c++) {
+            Step t{s.steps[4 * c], s.steps[4 * c + 1], s.steps[4 * c + 2], s.steps[4 * c + 3]};
+            if (t.op == SETK) {  // folded into the smooth joins it governs; re-materialised on emission
+                cur_k = (uint32_t)t.l;
+                continue;
+            }
+            if (t.op == SMIN || t.op == SMAX) t.k = cur_k;
+            in.push_back(t);
+        }
+    }
     // ---- fusion ------------------------------------------------------------------------------
     for (size_t i = 0; i < in.size(); i++) {
         const Step& a = in[i];
@@ -176,16 +229,18 @@ void optimise_program(Scene& s)
             int R = a.d;
             const Step& b = in[i + 1];
             // IMPORT -> R ; MIN|MAX x R -> x      (scenecompiler.py:372,377)
-            if ((b.op == MIN || b.op == MAX) && b.r == R && b.l == b.d && b.l != R && dead_after(in, i + 1, R)) {
-                out.push_back({b.op == MIN ? IMPORT_MIN : IMPORT_MAX, a.l, a.r, b.d});
+            if ((b.op == MIN || b.op == MAX || b.op == SMIN || b.op == SMAX) && b.r == R && b.l == b.d && b.l != R &&
+                dead_after(in, i + 1, R)) {
+                int f = b.op == MIN ? IMPORT_MIN : (b.op == MAX ? IMPORT_MAX : (b.op == SMIN ? IMPORT_SMIN : IMPORT_SMAX));
+                out.push_back({f, a.l, a.r, b.d, b.k});
                 i += 1;
                 continue;
             }
             // IMPORT -> R ; NEGATE R -> R ; MAX x R -> x   (scenecompiler.py:372-375)
             if (i + 2 < in.size() && b.op == NEGATE && b.l == R && b.d == R) {
                 const Step& m = in[i + 2];
-                if (m.op == MAX && m.r == R && m.l == m.d && m.l != R && dead_after(in, i + 2, R)) {
-                    out.push_back({IMPORT_NEGMAX, a.l, a.r, m.d});
+                if ((m.op == MAX || m.op == SMAX) && m.r == R && m.l == m.d && m.l != R && dead_after(in, i + 2, R)) {
+                    out.push_back({m.op == MAX ? IMPORT_NEGMAX : IMPORT_NEGSMAX, a.l, a.r, m.d, m.k});
                     i += 2;
                     continue;
                 }
@@ -199,7 +254,10 @@ void optimise_program(Scene& s)
     // Replaying the register program on a stack of slot names converts it; any step that does not fit
     // leaves stack_prog empty and the generic interpreter runs the register program instead.
     {
-        enum { PUSH = 32, ACC_MIN = 33, ACC_MAX = 34, ACC_NEGMAX = 35, POP_MIN = 36, POP_MAX = 37, POP_NEGMAX = 38, EXPORT_TOP = 39 };
+        enum {
+            PUSH = 32, ACC_MIN = 33, ACC_MAX = 34, ACC_NEGMAX = 35, POP_MIN = 36, POP_MAX = 37, POP_NEGMAX = 38, EXPORT_TOP = 39,
+            S_SETK = 40, ACC_SMIN = 41, ACC_SMAX = 42, ACC_NEGSMAX = 43, POP_SMIN = 44, POP_SMAX = 45, POP_NEGSMAX = 46
+        };
         std::vector<int> names;  // slot names, back() = top
         std::vector<Step> sp;
         bool ok = true;
@@ -220,19 +278,27 @@ void optimise_program(Scene& s)
                 if (n < 1 || names.back() != t.d) { ok = false; break; }
                 sp.push_back({t.op == IMPORT_MIN ? ACC_MIN : (t.op == IMPORT_MAX ? ACC_MAX : ACC_NEGMAX), t.l, t.r, n});
                 break;
+            case IMPORT_SMIN:
+            case IMPORT_SMAX:
+            case IMPORT_NEGSMAX:
+                if (n < 1 || names.back() != t.d) { ok = false; break; }
+                sp.push_back({t.op == IMPORT_SMIN ? ACC_SMIN : (t.op == IMPORT_SMAX ? ACC_SMAX : ACC_NEGSMAX), t.l, t.r, n, t.k});
+                break;
             case MIN:
             case MAX:  // joinMode parent child -> parent  (scenecompiler.py:384)
+            case SMIN:
+            case SMAX:
                 if (n < 2 || t.d != t.l || names[n - 2] != t.l || names[n - 1] != t.r || !dead_after(out, i, t.r)) { ok = false; break; }
-                sp.push_back({t.op == MIN ? POP_MIN : POP_MAX, 0, 0, n});
+                sp.push_back({t.op == MIN ? POP_MIN : (t.op == MAX ? POP_MAX : (t.op == SMIN ? POP_SMIN : POP_SMAX)), 0, 0, n, t.k});
                 names.pop_back();
                 break;
             case NEGATE: {  // NEGATE child -> R0 ; MAX parent R0 -> parent  (scenecompiler.py:381-382)
                 if (i + 1 >= out.size() || n < 2) { ok = false; break; }
                 const Step& m = out[i + 1];
                 int R = t.d;
-                if (names[n - 1] != t.l || on_stack(R) || m.op != MAX || m.r != R || m.l != m.d || names[n - 2] != m.l ||
-                    !dead_after(out, i + 1, R) || !dead_after(out, i + 1, t.l)) { ok = false; break; }
-                sp.push_back({POP_NEGMAX, 0, 0, n});
+                if (names[n - 1] != t.l || on_stack(R) || (m.op != MAX && m.op != SMAX) || m.r != R || m.l != m.d ||
+                    names[n - 2] != m.l || !dead_after(out, i + 1, R) || !dead_after(out, i + 1, t.l)) { ok = false; break; }
+                sp.push_back({m.op == MAX ? POP_NEGMAX : POP_NEGSMAX, 0, 0, n, m.k});
                 names.pop_back();
                 i += 1;
             } break;
@@ -249,19 +315,21 @@ void optimise_program(Scene& s)
         s.n_stack_prog = 0;
         s.stack_depth = 0;
         if (ok) {
+            uint32_t cur_k = 0;
             for (const Step& t : sp) {
+                if (t.k && t.k != cur_k) push_setk(s.stack_prog, S_SETK, cur_k = t.k);
                 s.stack_prog.push_back(t.op);
                 s.stack_prog.push_back(t.l);
                 s.stack_prog.push_back(t.r);
                 s.stack_prog.push_back(t.d);
             }
-            s.n_stack_prog = (int)sp.size();
+            s.n_stack_prog = (int)(s.stack_prog.size() / 4);
             s.stack_depth = depth_max;
         }
         // items: what the root accumulator sees -- single accumulate steps and whole groups
         s.items.clear();
         s.n_items = 0;
-        if (ok && depth_max <= 2) {
+        if (ok && depth_max <= 2 && !s.has_smooth) {  // smooth joins are not clamps: no culling (kernels.hip)
             bool fine = true;
             for (size_t k = 0; k < sp.size() && fine;) {
                 const Step& t = sp[k];
@@ -338,16 +406,23 @@ void optimise_program(Scene& s)
     }
     s.n_regs = reg_end.empty() ? 1 : (int)reg_end.size();
     s.prog.clear();
+    uint32_t cur_k = 0;
     for (const Step& t : out) {
         Step u = t;
+        if (t.k && t.k != cur_k) push_setk(s.prog, SETK, cur_k = t.k);
         switch (t.op) {
         case IMPORT:
         case IMPORT_MIN:
         case IMPORT_MAX:
-        case IMPORT_NEGMAX: u.d = map[t.d]; break;
+        case IMPORT_NEGMAX:
+        case IMPORT_SMIN:
+        case IMPORT_SMAX:
+        case IMPORT_NEGSMAX: u.d = map[t.d]; break;
         case EXPORT: u.l = map[t.l]; break;
         case MIN:
-        case MAX: u.l = map[t.l]; u.r = map[t.r]; u.d = map[t.d]; break;
+        case MAX:
+        case SMIN:
+        case SMAX: u.l = map[t.l]; u.r = map[t.r]; u.d = map[t.d]; break;
         case NEGATE:
         case IDENTITY: u.l = map[t.l]; u.d = map[t.d]; break;
         default: break;
@@ -357,7 +432,7 @@ void optimise_program(Scene& s)
         s.prog.push_back(u.r);
         s.prog.push_back(u.d);
     }
-    s.n_prog = (int)out.size();
+    s.n_prog = (int)(s.prog.size() / 4);
 }
 
 void build_blob(Scene& s, bool null_brush_is_const)

@@ -27,6 +27,7 @@ struct Scene {
     std::vector<int32_t> items;
     int n_items = 0;
     int max_brush_id = 0;                      // over IMPORT steps
+    bool has_smooth = false;                   // uses the extension opcodes SMOOTH_MIN / SMOOTH_MAX (6, 7; SET_K 8)
     std::vector<uint32_t> blob;                // uint4-granular, see kernels.hip "Scene tables in LDS"
     int blob_vec4() const { return (int)(blob.size() / 4); }
     size_t lds_bytes() const;                  // blob + interpreter stack

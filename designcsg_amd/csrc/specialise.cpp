@@ -23,8 +23,12 @@ static std::string hexf(float f)
 
 static void emit_function(const Scene& s, bool null_brush_const, int N, std::string& out)
 {
-    enum { PUSH = 32, ACC_MIN = 33, ACC_MAX = 34, ACC_NEGMAX = 35, POP_MIN = 36, POP_MAX = 37, POP_NEGMAX = 38, EXPORT_TOP = 39 };
-    char line[512];
+    enum {
+        PUSH = 32, ACC_MIN = 33, ACC_MAX = 34, ACC_NEGMAX = 35, POP_MIN = 36, POP_MAX = 37, POP_NEGMAX = 38, EXPORT_TOP = 39,
+        SETK = 40, ACC_SMIN = 41, ACC_SMAX = 42, ACC_NEGSMAX = 43, POP_SMIN = 44, POP_SMAX = 45, POP_NEGSMAX = 46
+    };
+    char line[768];
+    std::string kk = "0.0f", ikk = "0.0f";  // literals of the blend radius in force and of its reciprocal
     auto P = [&](const char* fmt, auto... a) {
         snprintf(line, sizeof(line), fmt, a...);
         out += line;
@@ -46,7 +50,22 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, std::str
     for (int c = 0; c < s.n_stack_prog; c++) {
         int op = s.stack_prog[4 * c], brush = s.stack_prog[4 * c + 1] & 0xff, obj = s.stack_prog[4 * c + 2],
             depth = s.stack_prog[4 * c + 3];
-        if (op >= PUSH && op <= ACC_NEGMAX) {
+        if (op == SETK) {
+            float k, ik;
+            memcpy(&k, &s.stack_prog[4 * c + 1], 4);
+            memcpy(&ik, &s.stack_prog[4 * c + 2], 4);
+            kk = hexf(k);
+            ikk = hexf(ik);
+            continue;
+        }
+        // smooth joins (extension; same expression order as dcsg_smin / dcsg_smax in kernels.hip)
+        auto smooth = [&](const std::string& dst, const std::string& a, const std::string& b, bool is_min) {
+            P("    { const float sa = %s, sb = %s; float st = %s - fabs(sa - sb); st = st > 0.0f ? st : 0.0f; "
+              "const float sh = st * %s; %s = (sa %s sb ? sa : sb) %s ((sh * sh) * %s) * 0.25f; }\n",
+              a.c_str(), b.c_str(), kk.c_str(), ikk.c_str(), dst.c_str(), is_min ? "<" : ">", is_min ? "-" : "+", kk.c_str());
+        };
+        auto S = [&](int d, int k) { return "s" + std::to_string(d) + "_" + std::to_string(k); };
+        if ((op >= PUSH && op <= ACC_NEGMAX) || (op >= ACC_SMIN && op <= ACC_NEGSMAX)) {
             int t = tmp++;
             out += "  {\n";
             if (brush == 0 && null_brush_const) {
@@ -72,16 +91,22 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, std::str
                 if (op == PUSH) P("    s%d_%d = r%d;\n", depth, k, k);
                 else if (op == ACC_MIN) P("    s%d_%d = s%d_%d < r%d ? s%d_%d : r%d;\n", depth - 1, k, depth - 1, k, k, depth - 1, k, k);
                 else if (op == ACC_MAX) P("    s%d_%d = s%d_%d > r%d ? s%d_%d : r%d;\n", depth - 1, k, depth - 1, k, k, depth - 1, k, k);
-                else P("    { const float nb = -r%d; s%d_%d = s%d_%d > nb ? s%d_%d : nb; }\n", k, depth - 1, k, depth - 1, k, depth - 1, k);
+                else if (op == ACC_NEGMAX) P("    { const float nb = -r%d; s%d_%d = s%d_%d > nb ? s%d_%d : nb; }\n", k, depth - 1, k, depth - 1, k, depth - 1, k);
+                else if (op == ACC_SMIN) smooth(S(depth - 1, k), S(depth - 1, k), "r" + std::to_string(k), true);
+                else if (op == ACC_SMAX) smooth(S(depth - 1, k), S(depth - 1, k), "r" + std::to_string(k), false);
+                else smooth(S(depth - 1, k), S(depth - 1, k), "(-r" + std::to_string(k) + ")", false);
             }
             out += "  }\n";
             (void)t;
-        } else if (op >= POP_MIN && op <= POP_NEGMAX) {
+        } else if ((op >= POP_MIN && op <= POP_NEGMAX) || (op >= POP_SMIN && op <= POP_NEGSMAX)) {
             for (int k = 0; k < N; k++) {
                 int a = depth - 2, b = depth - 1;
                 if (op == POP_MIN) P("  s%d_%d = s%d_%d < s%d_%d ? s%d_%d : s%d_%d;\n", a, k, a, k, b, k, a, k, b, k);
                 else if (op == POP_MAX) P("  s%d_%d = s%d_%d > s%d_%d ? s%d_%d : s%d_%d;\n", a, k, a, k, b, k, a, k, b, k);
-                else P("  { const float nb = -s%d_%d; s%d_%d = s%d_%d > nb ? s%d_%d : nb; }\n", b, k, a, k, a, k, a, k);
+                else if (op == POP_NEGMAX) P("  { const float nb = -s%d_%d; s%d_%d = s%d_%d > nb ? s%d_%d : nb; }\n", b, k, a, k, a, k, a, k);
+                else if (op == POP_SMIN) smooth(S(a, k), S(a, k), S(b, k), true);
+                else if (op == POP_SMAX) smooth(S(a, k), S(a, k), S(b, k), false);
+                else smooth(S(a, k), S(a, k), "(-" + S(b, k) + ")", false);
             }
         } else if (op == EXPORT_TOP) {
             for (int k = 0; k < N; k++) P("  o%d = s%d_%d;\n", k, depth - 1, k);

@@ -133,6 +133,30 @@ def eraseIntersection(*components, transform=Transform.identity()):
     _group(scenecompiler.IntersectionComponent, components, transform, True)
 
 
+# ---- extension of this package (not in the reference): smooth groups ------------------------------------
+# The children of the group are blended with the polynomial smooth minimum / maximum of radius k
+# (build-procedure opcodes 6-8); scenes using them are not readable by the reference.
+def _smooth_group(k, intersection, components, transform, subtractive):
+    kind = lambda **kw: scenecompiler.SmoothComponent(k, intersection, **kw)
+    _group(kind, components, transform, subtractive)
+
+
+def drawSmoothUnion(*components, k=0.1, transform=Transform.identity()):
+    _smooth_group(k, False, components, transform, False)
+
+
+def eraseSmoothUnion(*components, k=0.1, transform=Transform.identity()):
+    _smooth_group(k, False, components, transform, True)
+
+
+def drawSmoothIntersection(*components, k=0.1, transform=Transform.identity()):
+    _smooth_group(k, True, components, transform, False)
+
+
+def eraseSmoothIntersection(*components, k=0.1, transform=Transform.identity()):
+    _smooth_group(k, True, components, transform, True)
+
+
 def setExportConfig(boundingBoxHalfDiameter, minimumOctreeLevel, maximumOctreeLevel, gridLevel,
                     complexSurfaceThreshold, gradientDescentSteps=10, cacheSubdivision=16, queriesBeforeGC=64,
                     queriesBeforeFree=1024, meshSubdivisionLevel=4, maxPoolSize=0):

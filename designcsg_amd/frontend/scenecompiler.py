@@ -22,7 +22,9 @@ INITIAL_SCALE = 5.0
 ARBITRARY_DATA_POINTS = 131072
 
 # opcode numbers shared with the evaluator (k2.cl:12-17)
-COMMAND_VALUES = {"IMPORT": 0, "EXPORT": 1, "MIN": 2, "MAX": 3, "NEGATE": 4, "IDENTITY": 5}
+COMMAND_VALUES = {"IMPORT": 0, "EXPORT": 1, "MIN": 2, "MAX": 3, "NEGATE": 4, "IDENTITY": 5,
+                  # extension opcodes of this package (not in the reference; smooth joins)
+                  "SMOOTH_MIN": 6, "SMOOTH_MAX": 7, "SET_K": 8}
 
 
 def matmul(*mats):
@@ -283,6 +285,11 @@ class Component:
         if not self.children:
             return []
         me, r0 = self.variable, allocator.R0
+        blend = getattr(self, "blend", None)     # extension: smooth groups (SmoothComponent)
+        if blend is not None:
+            join = "SMOOTH_" + join
+            bits = int(np.array([blend], dtype="<f4").view("<i4")[0])
+            set_k = Command("SET_K", Argument.immediate(bits), Argument.immediate(0), Argument.immediate(0))
         cmds = [Command("IMPORT", Argument.immediate(self.brush.bank_index), Argument.immediate(self.unrolled_index), me)]
         for child in self.children:
             if child.children:
@@ -294,8 +301,13 @@ class Component:
                 source = r0
             if child.subtractive:
                 cmds.append(Command("NEGATE", source, Argument.null(), r0))
-                cmds.append(Command("MAX", me, r0, me))
+                if blend is not None:
+                    cmds.extend([set_k, Command("SMOOTH_MAX", me, r0, me)])
+                else:
+                    cmds.append(Command("MAX", me, r0, me))
             else:
+                if blend is not None:
+                    cmds.append(set_k)       # right before the join: a nested smooth group may have changed it
                 cmds.append(Command(join, me, source, me))
         return cmds
 
@@ -310,6 +322,25 @@ class _IntersectionComponent(Component):
 
     def get_commands(self, allocator):
         return super().get_commands(allocator, "MAX")
+
+
+class _SmoothComponent(Component):
+    """EXTENSION (not in the reference): group whose children are joined with the polynomial smooth minimum
+    (smooth union) of blend radius `blend`; with intersection=True it starts from the void brush and joins with
+    the smooth maximum.  The group itself joins its parent like any other group."""
+
+    def __init__(self, compiler, blend, intersection=False, **kwargs):
+        kwargs = dict(kwargs)
+        if not (np.isfinite(blend) and blend > 0):
+            raise ValueError("blend radius must be finite and > 0")
+        if intersection:
+            kwargs["brush"] = compiler.void_brush()
+        super().__init__(**kwargs)
+        self.blend = float(np.float32(blend))
+        self.intersection = intersection
+
+    def get_commands(self, allocator):
+        return super().get_commands(allocator, "MAX" if self.intersection else "MIN")
 
 
 class ArbitraryDataChunk:
@@ -451,3 +482,7 @@ def SceneCompiler():
 
 def IntersectionComponent(**kwargs):
     return _IntersectionComponent(compiler, **kwargs)
+
+
+def SmoothComponent(blend, intersection=False, **kwargs):
+    return _SmoothComponent(compiler, blend, intersection, **kwargs)

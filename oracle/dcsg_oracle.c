@@ -34,6 +34,16 @@
 #define OP_MAX 3
 #define OP_NEGATE 4
 #define OP_IDENTITY 5
+/* EXTENSION opcodes (not in the reference: scenecompiler.py:25-32 stops at IDENTITY, k2.cl's switch ignores
+ * anything else).  BASELINE.json's fifth configuration asks for "smooth-min unions"; they are defined HERE, and
+ * parity for them is GPU vs this restatement only (no reference output exists):
+ *   SET_K  bits          k = as_float(bits) (finite, > 0), inv_k = 1.0f / k
+ *   SMOOTH_MIN a b -> d  d = T_min(a,b) - ((h*h)*k)*0.25f,  h = T_max(k - fabs(a-b), 0) * inv_k
+ *   SMOOTH_MAX a b -> d  d = T_max(a,b) + ((h*h)*k)*0.25f
+ * all in float, left to right, no contraction (the polynomial smooth minimum with blend radius k).       */
+#define OP_SMOOTH_MIN 6
+#define OP_SMOOTH_MAX 7
+#define OP_SET_K 8
 #define STACK_MEMORY_PER_PIXEL 64 /* Evaluator.cpp:7 */
 
 /* OpenCL dot(float3,float3): x*x' + y*y' + z*z', left to right */
@@ -204,6 +214,7 @@ float oracle_primary_sdf(const oracle_scene *s, float x, float y, float z)
     float stack[STACK_MEMORY_PER_PIXEL];
     memset(stack, 0, sizeof(stack));
     float export_value = (float)K2_MAX_DISTANCE; /* k2.cl:91 */
+    float k = 0.0f, inv_k = 0.0f;                /* extension state, see OP_SET_K */
     for (int c = 0; c < s->n_steps; c++) {
         int op = s->steps[c * 4 + 0];
         int left = s->steps[c * 4 + 1];
@@ -233,6 +244,23 @@ float oracle_primary_sdf(const oracle_scene *s, float x, float y, float z)
         case OP_IDENTITY: /* k2.cl:132-134 */
             stack[dest] = stack[left];
             break;
+        case OP_SET_K: { /* extension */
+            int32_t bits = (int32_t)left;
+            memcpy(&k, &bits, 4);
+            inv_k = 1.0f / k;
+        } break;
+        case OP_SMOOTH_MIN:
+        case OP_SMOOTH_MAX: { /* extension */
+            float a = stack[left], b = stack[right];
+            float t = k - fabsf(a - b);
+            t = t > 0.0f ? t : 0.0f;
+            float h = t * inv_k;
+            float q = ((h * h) * k) * 0.25f;
+            if (op == OP_SMOOTH_MIN)
+                stack[dest] = (a < b ? a : b) - q;
+            else
+                stack[dest] = (a > b ? a : b) + q;
+        } break;
         default:
             break;
         }

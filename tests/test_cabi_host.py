@@ -164,11 +164,31 @@ def tmax(a, b):
     return np.where(a > b, a, b)
 
 
+def as_f32(bits):
+    return np.array([bits], dtype=np.int32).view(np.float32)[0]
+
+
+def smooth(a, b, k, inv_k, is_min):
+    """Extension opcodes SMOOTH_MIN / SMOOTH_MAX restated in numpy float32, one rounding per operation."""
+    t = k - np.abs(a - b)
+    t = np.where(t > np.float32(0), t, np.float32(0)).astype(np.float32)
+    h = t * inv_k
+    q = ((h * h) * k) * np.float32(0.25)
+    return (tmin(a, b) - q) if is_min else (tmax(a, b) + q)
+
+
 def run_register_program(prog, n_regs, imp, n):
     st = np.zeros((max(n_regs, 1), n), dtype=np.float32)
     out = np.full(n, 64.0, dtype=np.float32)
+    k = inv_k = np.float32(0)
     for op, l, r, d in prog.tolist():
-        if op == 0: st[d] = imp[(l & 255, r)]
+        if op == 8: k, inv_k = as_f32(l), as_f32(r)
+        elif op == 6: st[d] = smooth(st[l], st[r], k, inv_k, True)
+        elif op == 7: st[d] = smooth(st[l], st[r], k, inv_k, False)
+        elif op == 19: st[d] = smooth(st[d], imp[(l & 255, r)], k, inv_k, True)
+        elif op == 20: st[d] = smooth(st[d], imp[(l & 255, r)], k, inv_k, False)
+        elif op == 21: st[d] = smooth(st[d], -imp[(l & 255, r)], k, inv_k, False)
+        elif op == 0: st[d] = imp[(l & 255, r)]
         elif op == 16: st[d] = tmin(st[d], imp[(l & 255, r)])
         elif op == 17: st[d] = tmax(st[d], imp[(l & 255, r)])
         elif op == 18: st[d] = tmax(st[d], -imp[(l & 255, r)])
@@ -183,9 +203,19 @@ def run_register_program(prog, n_regs, imp, n):
 def run_stack_program(prog, imp, n):
     st = []
     out = np.full(n, 64.0, dtype=np.float32)
+    k = inv_k = np.float32(0)
     for op, l, r, depth in prog.tolist():
+        if op == 40:
+            k, inv_k = as_f32(l), as_f32(r)
+            continue
         assert depth == len(st), "recorded depth must equal the stack depth before the step"
-        if op == 32: st.append(imp[(l & 255, r)].copy())
+        if op == 41: st[-1] = smooth(st[-1], imp[(l & 255, r)], k, inv_k, True)
+        elif op == 42: st[-1] = smooth(st[-1], imp[(l & 255, r)], k, inv_k, False)
+        elif op == 43: st[-1] = smooth(st[-1], -imp[(l & 255, r)], k, inv_k, False)
+        elif op in (44, 45, 46):
+            v = st.pop()
+            st[-1] = smooth(st[-1], v, k, inv_k, True) if op == 44 else smooth(st[-1], v if op == 45 else -v, k, inv_k, False)
+        elif op == 32: st.append(imp[(l & 255, r)].copy())
         elif op == 33: st[-1] = tmin(st[-1], imp[(l & 255, r)])
         elif op == 34: st[-1] = tmax(st[-1], imp[(l & 255, r)])
         elif op == 35: st[-1] = tmax(st[-1], -imp[(l & 255, r)])
@@ -246,6 +276,66 @@ def test_program_optimiser_on_hand_written_programs(built_lib, oracle):
             assert np.array_equal(run_stack_program(stk, imp, len(pts)).view(np.uint32), want.view(np.uint32)), key
     assert len(compile_program(built_lib, scene_txt, cases["live_r0"])[3]) == 0
     assert [s[0] for s in compile_program(built_lib, scene_txt, cases["swapped"])[1].tolist()] == [0, 0, 2, 1]
+
+
+SMOOTH_SCENES = ["smooth_blobs", "smooth256"]   # extension fixtures (tests/golden/make_extension_fixtures.py)
+
+
+@pytest.mark.parametrize("name", SMOOTH_SCENES)
+def test_smooth_extension_programs(built_lib, oracle, name):
+    """Smooth joins (extension opcodes 6-8, not in the reference).  Three independent statements of the same
+    arithmetic must agree bit for bit: the oracle's interpreter on the original buildprocedure.txt, and the numpy
+    float32 restatement above run on the host's fused register program and on its stack program."""
+    sc = read_scene(name)
+    sc["dir"] = scene_dir(name)
+    rc, reg, n_regs, stk, depth = compile_program(built_lib, sc["scene.txt"], sc["buildprocedure.txt"])
+    assert rc == 0 and len(stk) > 0 and depth in (2, 3)
+    ops = set(stk[:, 0].tolist())
+    assert 40 in ops and ops & {41, 42, 43}
+    # one SET_K per change of radius, not one per join
+    n_join = sum(1 for o in stk[:, 0].tolist() if 41 <= o <= 46)
+    assert sum(1 for o in stk[:, 0].tolist() if o == 40) == {"smooth_blobs": 4, "smooth256": 8}[name] < n_join
+    rng = np.random.default_rng(14)
+    pts = rng.uniform(-5, 5, (3000 if name == "smooth256" else 20000, 3)).astype(np.float32)
+    pts[: len(pts) // 2] *= np.float32(0.6)     # more samples inside the blend zones
+    want = oracle.Scene.from_dir(scene_dir(name)).eval_sdf(pts)
+    imp = object_values(oracle, sc, pts)
+    assert np.array_equal(run_register_program(reg, n_regs, imp, len(pts)).view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(run_stack_program(stk, imp, len(pts)).view(np.uint32), want.view(np.uint32))
+    # the blend actually happens somewhere: the smooth result differs from the hard one
+    hard = sc["buildprocedure.txt"].replace("\n6 ", "\n2 ").replace("\n7 ", "\n3 ")
+    ref = oracle.Scene(sc["scene.txt"], hard, os.path.join(sc["dir"], "scene.cl")).eval_sdf(pts)
+    assert np.count_nonzero(ref != want) > len(pts) // 50
+
+
+def test_smooth_extension_hand_written(built_lib, oracle):
+    scene_txt = read_scene("mixed_groups")["scene.txt"]
+    k1 = int(np.array([0.25], dtype=np.float32).view(np.int32)[0])
+    k2 = int(np.array([1.5], dtype=np.float32).view(np.int32)[0])
+    cases = {
+        # unfused smooth ops on plain slots, radius changed in between, dest != left
+        "plain": "0 2 1 0\n0 3 2 1\n8 %d 0 0\n6 0 1 2\n8 %d 0 0\n7 2 1 3\n6 3 0 0\n1 0 -1 -1" % (k1, k2),
+        # operands swapped: must not be fused, same bits as the oracle
+        "swapped": "0 4 3 0\n0 2 1 1\n8 %d 0 0\n6 1 0 0\n1 0 -1 -1" % k1,
+        # leaf joins that fuse, incl. the carved (NEGATE + SMOOTH_MAX) form, then a hard join
+        "fused": "0 0 0 0\n0 2 1 1\n8 %d 0 0\n6 0 1 0\n0 3 2 1\n4 1 -1 1\n8 %d 0 0\n7 0 1 0\n0 4 3 1\n2 0 1 0\n1 0 -1 -1" % (k1, k1),
+    }
+    rng = np.random.default_rng(19)
+    pts = rng.uniform(-3, 3, (5000, 3)).astype(np.float32)
+    sc = {"scene.txt": scene_txt, "dir": scene_dir("mixed_groups")}
+    imp = object_values(oracle, sc, pts)
+    for key, bp in cases.items():
+        rc, reg, n_regs, stk, depth = compile_program(built_lib, scene_txt, bp)
+        assert rc == 0, key
+        want = oracle.Scene(scene_txt, bp, os.path.join(sc["dir"], "scene.cl")).eval_sdf(pts)
+        assert np.array_equal(run_register_program(reg, n_regs, imp, len(pts)).view(np.uint32), want.view(np.uint32)), key
+        if len(stk):
+            assert np.array_equal(run_stack_program(stk, imp, len(pts)).view(np.uint32), want.view(np.uint32)), key
+    assert [s[0] for s in compile_program(built_lib, scene_txt, cases["fused"])[1].tolist()] == [0, 8, 19, 21, 16, 1]
+    # malformed: smooth join before any SET_K; radius zero / negative / NaN / inf
+    for bad in ("0 2 1 0\n0 3 2 1\n6 0 1 0\n1 0 -1 -1", "8 0 0 0\n1 0 -1 -1", "8 -1082130432 0 0\n1 0 -1 -1",
+                "8 2143289344 0 0\n1 0 -1 -1", "8 2139095040 0 0\n1 0 -1 -1"):
+        assert compile_program(built_lib, scene_txt, bad)[0] != 0, bad
 
 
 def test_scene_validation(built_lib):

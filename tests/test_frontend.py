@@ -33,6 +33,15 @@ def test_own_design_scripts_reproduce_reference_output(name, tmp_path):
     assert hashlib.sha256(ad).hexdigest() == MANIFEST[name]["arbitrary_data_sha256"]
 
 
+@pytest.mark.parametrize("name", ["smooth_blobs", "smooth256"])
+def test_extension_fixtures_are_what_the_front_end_writes(name, tmp_path):
+    """Smooth-join scenes (extension, tests/golden/make_extension_fixtures.py) are compiled by this front-end;
+    the committed fixtures must be its current output."""
+    run(os.path.join(DESIGNS, name + ".py"), tmp_path)
+    for f in FILES:
+        assert (tmp_path / f).read_bytes() == open(os.path.join(SCENES, name, f), "rb").read(), f
+
+
 def _bodies(scene_cl, kind):
     """Brush / material bodies of a generated scene.cl, in bank order."""
     pat = r"float sd(\d+)\( float3 v\)\{\n\n            (.*?)\n\n        \}" if kind == "sd" else \

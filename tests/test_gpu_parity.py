@@ -11,7 +11,8 @@ from conftest import export_config_text, read_scene, scene_dir
 
 pytestmark = pytest.mark.gpu
 
-ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table", "prefabs", "const_table"]
+ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table", "prefabs", "const_table",
+              "smooth_blobs", "smooth256"]   # the last two: smooth-join extension, parity vs the oracle only
 STL_TOL = 1e-5  # north_star: ".stl diff within 1e-5"
 
 
@@ -41,10 +42,10 @@ def sorted_tris(t):
 
 
 EXPECTED_STACK_DEPTH = {"sphere": 1, "design1": 1, "design2": 1, "flat256": 1, "mixed_groups": 2, "grouped256": 2,
-                        "ad_table": 1, "prefabs": 2, "const_table": 1}
+                        "ad_table": 1, "prefabs": 2, "const_table": 1, "smooth_blobs": 3, "smooth256": 2}
 
 
-SPECIALISED = {"sphere", "design1", "design2", "mixed_groups", "ad_table", "prefabs", "const_table"}  # <= 48 object evaluations
+SPECIALISED = {"sphere", "design1", "design2", "mixed_groups", "ad_table", "prefabs", "const_table", "smooth_blobs"}  # <= 48 object evaluations
 
 
 @pytest.mark.parametrize("interpreter", ["auto", "stack", "generic"])
@@ -71,6 +72,8 @@ def test_point_eval_bit_exact(ev, oracle, name, interpreter, monkeypatch):
     rng = np.random.default_rng(7)
     n = 200_000 if name in ("sphere", "design1", "design2") else 40_000
     pts = rng.uniform(-5.0, 5.0, (n, 3)).astype(np.float32)
+    if name.startswith("smooth"):
+        pts[n // 2:] *= np.float32(0.5)     # more samples inside the blend zones
     # include the golden probe points of SURVEY 8(c) and exact symmetry points (normalize(0) = 0)
     pts[:6] = [(0, 0, 0), (1, 0, 0), (0, -4.3, 0), (2.5, 2.5, 2.5), (0.3, 0.1, -0.7), (-0.0, 0.0, -0.0)]
     got_s, got_n = ev.eval_sdf_at_points(pts), ev.eval_normal_at_points(pts)
@@ -94,7 +97,7 @@ def test_builtin_bank_equals_jit_bank(ev, oracle):
     assert np.array_equal(bits(a), bits(b))
 
 
-@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table", "const_table", "flat256", "grouped256"])
+@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table", "const_table", "smooth_blobs", "flat256", "grouped256"])
 def test_lattice_sweep_bit_exact(ev, oracle, name):
     load(ev, name)
     osc = oracle.Scene.from_dir(scene_dir(name))
@@ -154,7 +157,7 @@ GOLD_TRIS_128 = {  # levels 4/6/7, per-level triangle counts
 }
 
 
-@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups", "ad_table", "const_table"])
+@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups", "ad_table", "const_table", "smooth_blobs"])
 @pytest.mark.parametrize("dense_normals", [False, True])
 def test_mesher_and_projection_bit_exact(ev, oracle, lookup_table, name, dense_normals, tmp_path):
     load(ev, name)
