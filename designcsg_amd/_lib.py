@@ -14,6 +14,9 @@ ARBITRARY_DATA_POINTS = 131072
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_BUILD, ERR_NO_SCENE, ERR_IO = 0, -1, -2, -3, -4, -5, -6
 EXPORT_DENSE_NORMALS = 1
+EXPORT_SPARSE_NORMALS = 2
+EXPORT_INDEXED_PLY = 4     # opt-in writers beyond the reference's, include/dcsg.h
+EXPORT_STL_NORMALS = 8
 
 
 class ExportConfig(C.Structure):
@@ -70,6 +73,8 @@ PROTOTYPES = {
     "dcsg_copy_triangles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "dcsg_write_stl": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
     "dcsg_write_ply": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
+    "dcsg_write_stl_normals": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
+    "dcsg_write_ply_indexed": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "dcsg_parse_export_config": (C.c_int, [C.c_char_p, C.POINTER(ExportConfig)]),
     "dcsg_export": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint, C.POINTER(ExportStats)]),
     "dcsg_last_sweep_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

@@ -971,6 +971,111 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
     return (close(fd) == 0 && ok) ? 0 : DCSG_ERR_IO;
 }
 
+// ---- opt-in writers beyond the reference's -----------------------------------------------
+// STL with real facet normals: same records as dcsg_write_stl, the normal = normalize(cross(B-A, C-A)) of the
+// vertices AS WRITTEN (x, z, y), in float, left to right; degenerate facets keep the zero normal.
+int dcsg_write_stl_normals(const char* path, const float* tris, uint64_t n)
+{
+    if (!path || (n && !tris)) return DCSG_ERR_INVALID;
+    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return DCSG_ERR_IO;
+    unsigned char head[84];
+    memset(head, 0, sizeof(head));
+    uint32_t n32 = (uint32_t)n;
+    memcpy(head + 80, &n32, 4);
+    bool ok = pwrite_all(fd, head, sizeof(head), 0);
+    ok = ok && parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
+        const uint64_t step = 1u << 15;
+        std::vector<unsigned char> buf((size_t)step * 50);
+        for (uint64_t a = t0; a < t1; a += step) {
+            uint64_t b = a + step < t1 ? a + step : t1;
+            unsigned char* o = buf.data();
+            for (uint64_t t = a; t < b; t++, o += 50) {
+                const float* v = tris + t * 9;
+                float rec[12] = {0.0f, 0.0f, 0.0f, v[0], v[2], v[1], v[3], v[5], v[4], v[6], v[8], v[7]};
+                float ux = rec[6] - rec[3], uy = rec[7] - rec[4], uz = rec[8] - rec[5];
+                float wx = rec[9] - rec[3], wy = rec[10] - rec[4], wz = rec[11] - rec[5];
+                float nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
+                float len = sqrtf(nx * nx + ny * ny + nz * nz);
+                if (len > 0.0f && len - len == 0.0f) {
+                    rec[0] = nx / len;
+                    rec[1] = ny / len;
+                    rec[2] = nz / len;
+                }
+                memcpy(o, rec, 48);
+                o[48] = o[49] = 0;
+            }
+            if (!pwrite_all(fd, buf.data(), (size_t)(b - a) * 50, (off_t)(84 + a * 50))) return false;
+        }
+        return true;
+    });
+    return (close(fd) == 0 && ok) ? 0 : DCSG_ERR_IO;
+}
+
+// Indexed PLY: every distinct vertex position (bit pattern) once, in order of first appearance, as float
+// x y z; faces index them.  Same axis order as dcsg_write_ply (x, y, z as stored, no swap).
+int dcsg_write_ply_indexed(const char* path, const float* tris, uint64_t n, uint64_t* n_unique_out)
+{
+    if (!path || (n && !tris)) return DCSG_ERR_INVALID;
+    if (n * 3 >= 0xffffffffull) return DCSG_ERR_INVALID;
+    // open-addressing table over the 96-bit position; value = vertex id
+    uint64_t cap = 16;
+    while (cap < n * 3 * 2) cap <<= 1;
+    std::vector<uint32_t> slot(cap, 0xffffffffu);
+    std::vector<uint32_t> index(n * 3);
+    std::vector<float> verts;
+    verts.reserve((size_t)(n * 3 / 4 + 16) * 3);
+    for (uint64_t i = 0; i < n * 3; i++) {
+        uint32_t w[3];
+        memcpy(w, tris + i * 3, 12);
+        uint64_t h = fnv1a64(w, 12, 0x9e3779b97f4a7c15ull) & (cap - 1);
+        for (;;) {
+            uint32_t id = slot[h];
+            if (id == 0xffffffffu) {
+                id = (uint32_t)(verts.size() / 3);
+                slot[h] = id;
+                verts.insert(verts.end(), tris + i * 3, tris + i * 3 + 3);
+                index[i] = id;
+                break;
+            }
+            if (memcmp(&verts[(size_t)id * 3], w, 12) == 0) {
+                index[i] = id;
+                break;
+            }
+            h = (h + 1) & (cap - 1);
+        }
+    }
+    const uint64_t nv = verts.size() / 3;
+    if (n_unique_out) *n_unique_out = nv;
+    char header[512];
+    int hl = snprintf(header, sizeof(header),
+                      "ply\nformat binary_little_endian 1.0\ncomment designcsg-amd indexed mesh\n"
+                      "element vertex %llu\nproperty float x\nproperty float y\nproperty float z\n"
+                      "element face %llu\nproperty list uchar uint vertex_indices\nend_header\n",
+                      (unsigned long long)nv, (unsigned long long)n);
+    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return DCSG_ERR_IO;
+    bool ok = pwrite_all(fd, (const unsigned char*)header, (size_t)hl, 0);
+    ok = ok && pwrite_all(fd, (const unsigned char*)verts.data(), (size_t)nv * 12, hl);
+    const off_t faces_at = hl + (off_t)(nv * 12);
+    const uint32_t* idx = index.data();
+    ok = ok && parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
+        const uint64_t step = 1u << 16;
+        std::vector<unsigned char> fbuf((size_t)step * 13);
+        for (uint64_t a = t0; a < t1; a += step) {
+            uint64_t b = a + step < t1 ? a + step : t1;
+            unsigned char* q = fbuf.data();
+            for (uint64_t t = a; t < b; t++, q += 13) {
+                q[0] = 3;
+                memcpy(q + 1, idx + 3 * t, 12);
+            }
+            if (!pwrite_all(fd, fbuf.data(), (size_t)(b - a) * 13, faces_at + (off_t)(a * 13))) return false;
+        }
+        return true;
+    });
+    return (close(fd) == 0 && ok) ? 0 : DCSG_ERR_IO;
+}
+
 int dcsg_debug_sqrt_device(dcsg_ctx* c, const float* d_in, size_t n, float* d_out, void* stream)
 {
     if (!c || n > 0xffffff00ull) return DCSG_ERR_INVALID;
@@ -1119,12 +1224,14 @@ int dcsg_export(dcsg_ctx* c, const char* cfg_txt, const char* stl_path, const ch
         if (ply_path)
             ply_thread = std::thread([&] {
                 double a = now_s();
-                rc_ply = dcsg_write_ply(ply_path, host, n_tris);
+                rc_ply = (flags & DCSG_EXPORT_INDEXED_PLY) ? dcsg_write_ply_indexed(ply_path, host, n_tris, nullptr)
+                                                           : dcsg_write_ply(ply_path, host, n_tris);
                 dt_ply = now_s() - a;
             });
         if (stl_path) {
             double a = now_s();
-            rc_stl = dcsg_write_stl(stl_path, host, n_tris);
+            rc_stl = (flags & DCSG_EXPORT_STL_NORMALS) ? dcsg_write_stl_normals(stl_path, host, n_tris)
+                                                       : dcsg_write_stl(stl_path, host, n_tris);
             dt_stl = now_s() - a;
         }
         if (ply_thread.joinable()) ply_thread.join();

@@ -631,13 +631,17 @@ __device__ __forceinline__ DcsgClamp2 dcsg_clamp_wave_scan(DcsgClamp2 v)
     return v;
 }
 
-// keep test of a step given the interval [lo, hi] of the accumulator before it
-__device__ __forceinline__ bool dcsg_step_keep(int op, float lb, float ub, float lo, float hi)
+// keep test of a step given the interval [lo, hi] of the accumulator before it (k = blend radius in force)
+__device__ __forceinline__ bool dcsg_step_keep(int op, float lb, float ub, float lo, float hi, float k = 0.0f)
 {
     if (op == SOP_ACC_MIN) return !(lb > hi);    // T_min(a, s) = a wherever a < s
     if (op == SOP_ACC_MAX) return !(ub < lo);    // T_max(a, s) = a wherever a > s
     if (op == SOP_ACC_NEGMAX) return !(-lb < lo);
-    return op >= 0;                              // PUSH, POP, EXPORT: always
+    // smooth joins return the accumulator unchanged wherever |a - s| >= k on the accumulator's side (h = 0)
+    if (op == SOP_ACC_SMIN) return !(lb - hi > k);
+    if (op == SOP_ACC_SMAX) return !(lo - ub > k);
+    if (op == SOP_ACC_NEGSMAX) return !(lo + lb > k);
+    return op >= 0;                              // PUSH, POP, EXPORT, SET_K: always
 }
 
 // value of one PUSH / ACC step at the tile centre with its margin: s in [lb, ub] over the tile
@@ -685,16 +689,35 @@ __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, 
     if (count == 1) {
         dcsg_step_bounds(s, s.stack_steps[first], cx, cy, cz, R, lb, ub);
     } else {
-        float glo = 0.0f, ghi = 0.0f;
+        float glo = 0.0f, ghi = 0.0f, gk = 0.0f, gq = 0.0f;
         const bool small = count <= 64;
         mask = small ? (1ull << (count - 1)) : ~0ull;  // the POP always runs
         for (int j = 0; j < count - 1; j++) {
             int4 st = s.stack_steps[first + j];
+            if (st.x == SOP_SET_K) {  // radius of the smooth joins that follow; always runs
+                gk = __int_as_float(st.y);
+                gq = 0.25f * gk * 1.001f + 1e-6f;  // >= the largest amount a smooth join moves past min / max
+                if (small) mask |= 1ull << j;
+                continue;
+            }
             float b0, b1;
             dcsg_step_bounds(s, st, cx, cy, cz, R, b0, b1);
-            bool keep = dcsg_step_keep(st.x, b0, b1, glo, ghi);
+            bool keep = dcsg_step_keep(st.x, b0, b1, glo, ghi, gk);
             if (keep && small) mask |= 1ull << j;
-            if (st.x == SOP_PUSH) {
+            if (st.x >= SOP_ACC_SMIN) {  // smooth accumulates: unchanged when dropped, else min / max widened by gq
+                if (keep) {
+                    if (st.x == SOP_ACC_SMIN) {
+                        glo = fminf(glo, b0) - gq;
+                        ghi = fminf(ghi, b1);
+                    } else if (st.x == SOP_ACC_SMAX) {
+                        glo = fmaxf(glo, b0);
+                        ghi = fmaxf(ghi, b1) + gq;
+                    } else {
+                        glo = fmaxf(glo, -b1);
+                        ghi = fmaxf(ghi, -b0) + gq;
+                    }
+                }
+            } else if (st.x == SOP_PUSH) {
                 glo = b0;
                 ghi = b1;
             } else if (st.x == SOP_ACC_MIN) {

@@ -317,6 +317,9 @@ void optimise_program(Scene& s)
         if (ok) {
             uint32_t cur_k = 0;
             for (const Step& t : sp) {
+                // every group loads the radius it needs itself (a PUSH forgets the one in force): the tile culling
+                // drops whole groups, and a later group must not depend on a SET_K inside a dropped one
+                if (t.op == PUSH) cur_k = 0;
                 if (t.k && t.k != cur_k) push_setk(s.stack_prog, S_SETK, cur_k = t.k);
                 s.stack_prog.push_back(t.op);
                 s.stack_prog.push_back(t.l);
@@ -326,33 +329,42 @@ void optimise_program(Scene& s)
             s.n_stack_prog = (int)(s.stack_prog.size() / 4);
             s.stack_depth = depth_max;
         }
-        // items: what the root accumulator sees -- single accumulate steps and whole groups
+        // items: what the root accumulator sees -- single accumulate steps and whole groups (indices into the
+        // emitted stack_prog, SET_K steps included).  Smooth joins are allowed INSIDE a group (its steps are walked
+        // with interval arithmetic, kernels.hip dcsg_item_clamp); the root's own joins must be the hard ones, whose
+        // action on an interval is a clamp.
         s.items.clear();
         s.n_items = 0;
-        if (ok && depth_max <= 2 && !s.has_smooth) {  // smooth joins are not clamps: no culling (kernels.hip)
+        if (ok && depth_max <= 2) {
             bool fine = true;
-            for (size_t k = 0; k < sp.size() && fine;) {
-                const Step& t = sp[k];
-                if (t.op == PUSH && t.d == 0) {
+            const std::vector<int32_t>& q = s.stack_prog;
+            const size_t nq = q.size() / 4;
+            auto OP = [&](size_t k) { return q[4 * k]; };
+            auto DEPTH = [&](size_t k) { return q[4 * k + 3]; };
+            for (size_t k = 0; k < nq && fine;) {
+                int op = OP(k);
+                if (op == PUSH && DEPTH(k) == 0) {
                     s.items.insert(s.items.end(), {(int)k, 1, PUSH, 0});
                     k++;
-                } else if (t.op >= ACC_MIN && t.op <= ACC_NEGMAX && t.d == 1) {
-                    s.items.insert(s.items.end(), {(int)k, 1, t.op, 0});
+                } else if (op >= ACC_MIN && op <= ACC_NEGMAX && DEPTH(k) == 1) {
+                    s.items.insert(s.items.end(), {(int)k, 1, op, 0});
                     k++;
-                } else if (t.op == PUSH && t.d == 1) {
+                } else if (op == PUSH && DEPTH(k) == 1) {
                     size_t e = k + 1;
-                    while (e < sp.size() && !(sp[e].op >= POP_MIN && sp[e].op <= POP_NEGMAX)) {
-                        if (!(sp[e].op >= ACC_MIN && sp[e].op <= ACC_NEGMAX)) fine = false;
+                    while (e < nq && !((OP(e) >= POP_MIN && OP(e) <= POP_NEGMAX) || (OP(e) >= POP_SMIN && OP(e) <= POP_NEGSMAX))) {
+                        bool member = (OP(e) >= ACC_MIN && OP(e) <= ACC_NEGMAX) || (OP(e) >= ACC_SMIN && OP(e) <= ACC_NEGSMAX) ||
+                                      OP(e) == S_SETK;
+                        if (!member) fine = false;
                         e++;
                     }
-                    if (e >= sp.size()) fine = false;
-                    if (fine) s.items.insert(s.items.end(), {(int)k, (int)(e - k + 1), sp[e].op, 0});
+                    if (e >= nq || OP(e) > POP_NEGMAX) fine = false;  // a smooth join into the root is not a clamp
+                    if (fine) s.items.insert(s.items.end(), {(int)k, (int)(e - k + 1), OP(e), 0});
                     k = e + 1;
-                } else if (t.op == EXPORT_TOP) {
+                } else if (op == EXPORT_TOP) {
                     s.items.insert(s.items.end(), {(int)k, 1, EXPORT_TOP, 0});
                     k++;
                 } else {
-                    fine = false;
+                    fine = false;  // incl. smooth accumulates or SET_K at root level
                 }
             }
             if (fine)

@@ -180,13 +180,16 @@ class Evaluator:
     def debug_sqrt_device(self, d_in, n, d_out, stream=0):
         self._ck(self._L.dcsg_debug_sqrt_device(self._h, C.c_void_p(d_in), n, C.c_void_p(d_out), C.c_void_p(stream or None)))
 
-    def export(self, export_config_txt, stl_path=None, ply_path=None, dense_normals=False):
-        """MyFrame::OnExportInner end to end on this GPU."""
+    def export(self, export_config_txt, stl_path=None, ply_path=None, dense_normals=False, indexed_ply=False,
+               stl_normals=False):
+        """MyFrame::OnExportInner end to end on this GPU.  indexed_ply / stl_normals select the opt-in writers
+        (shared vertices; real facet normals) instead of the reference's file layouts."""
         st = ExportStats()
+        flags = (_lib.EXPORT_DENSE_NORMALS if dense_normals else 0) | (_lib.EXPORT_INDEXED_PLY if indexed_ply else 0) | \
+            (_lib.EXPORT_STL_NORMALS if stl_normals else 0)
         self._ck(self._L.dcsg_export(self._h, export_config_txt.encode(),
                                      None if stl_path is None else os.fsencode(stl_path),
-                                     None if ply_path is None else os.fsencode(ply_path),
-                                     _lib.EXPORT_DENSE_NORMALS if dense_normals else 0, C.byref(st)))
+                                     None if ply_path is None else os.fsencode(ply_path), flags, C.byref(st)))
         return st
 
 
@@ -209,3 +212,21 @@ def write_ply(path, tris):
     rc = _lib.lib().dcsg_write_ply(os.fsencode(path), _fptr(t), t.size // 9)
     if rc:
         raise DcsgError(rc, "cannot write " + str(path))
+
+
+def write_stl_normals(path, tris):
+    """Opt-in: STL with facet normals (the reference writes zero normals)."""
+    t = np.ascontiguousarray(tris, dtype=np.float32)
+    rc = _lib.lib().dcsg_write_stl_normals(os.fsencode(path), _fptr(t), t.size // 9)
+    if rc:
+        raise DcsgError(rc, "cannot write " + str(path))
+
+
+def write_ply_indexed(path, tris):
+    """Opt-in: PLY with shared vertices (the reference repeats every vertex per face).  Returns the vertex count."""
+    t = np.ascontiguousarray(tris, dtype=np.float32)
+    nv = C.c_uint64(0)
+    rc = _lib.lib().dcsg_write_ply_indexed(os.fsencode(path), _fptr(t), t.size // 9, C.byref(nv))
+    if rc:
+        raise DcsgError(rc, "cannot write " + str(path))
+    return nv.value

@@ -145,6 +145,11 @@ int dcsg_copy_triangles_device(dcsg_ctx* ctx, float* d_out, uint64_t max_triangl
 /* cms::writeTrianglesToSTL (utils.hpp:41-103) / writeTrianglesToPLY (utils.hpp:106-154). */
 int dcsg_write_stl(const char* path, const float* triangles, uint64_t n_triangles);
 int dcsg_write_ply(const char* path, const float* triangles, uint64_t n_triangles);
+/* Opt-in writers beyond the reference's (its STL has zero normals, its PLY repeats every vertex per face):
+ * STL with facet normals normalize(cross(B-A, C-A)) of the vertices as written; PLY with every distinct
+ * position once (float x y z, order of first appearance) and faces indexing them. */
+int dcsg_write_stl_normals(const char* path, const float* triangles, uint64_t n_triangles);
+int dcsg_write_ply_indexed(const char* path, const float* triangles, uint64_t n_triangles, uint64_t* n_unique_vertices);
 
 int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* out);
 /* MyFrame::OnExportInner (DesignCSG.cpp:638-790) end to end on one GPU: stage A, lattice sweep,
@@ -152,6 +157,8 @@ int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* 
  * stl_path / ply_path may be NULL to skip a writer.  flags: DCSG_EXPORT_*. */
 #define DCSG_EXPORT_DENSE_NORMALS 1u  /* sweep normals for every lattice point instead of on demand */
 #define DCSG_EXPORT_SPARSE_NORMALS 2u /* never sweep normals densely (default: dense only for culled scenes) */
+#define DCSG_EXPORT_INDEXED_PLY 4u    /* ply_path gets dcsg_write_ply_indexed instead of the reference layout */
+#define DCSG_EXPORT_STL_NORMALS 8u    /* stl_path gets dcsg_write_stl_normals instead of zero normals */
 int dcsg_export(dcsg_ctx* ctx, const char* export_config_txt, const char* stl_path, const char* ply_path,
                 unsigned flags, dcsg_export_stats* stats);
 

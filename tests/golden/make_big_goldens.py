@@ -16,7 +16,8 @@ from oracle import oracle as O  # noqa: E402
 TABLE = O.LookupTable(open(os.path.join(HERE, "..", "..", "designcsg_amd", "data", "lookupTable.txt")).read())
 RUNS = {"sphere_6_8_9": ("sphere", (6, 8, 9)), "design2_6_8_9": ("design2", (6, 8, 9)),
         "design2_7_9_10": ("design2", (7, 9, 10)), "flat256_6_8_9": ("flat256", (6, 8, 9)),
-        "grouped256_6_8_9": ("grouped256", (6, 8, 9))}
+        "grouped256_6_8_9": ("grouped256", (6, 8, 9)),
+        "smooth256_6_8_9": ("smooth256", (6, 8, 9))}   # smooth-join extension: oracle-defined, no reference figure
 
 
 def tri_set_hash(tris):
@@ -26,8 +27,13 @@ def tri_set_hash(tris):
 
 
 def main():
-    out = {}
+    """No arguments: all runs.  With arguments: only those keys, merged into the existing file."""
+    path = os.path.join(HERE, "big_configs.json")
+    only = sys.argv[1:]
+    out = json.load(open(path)) if only else {}
     for key, (name, levels) in RUNS.items():
+        if only and key not in only:
+            continue
         d = os.path.join(HERE, "scenes", name)
         sc = O.Scene.from_dir(d)
         cfg = O.parse_export_config(open(os.path.join(d, "exportConfig.txt")).read())
@@ -47,7 +53,7 @@ def main():
             "gd50_nan": int(np.isnan(v).sum()),
         }
         print(key, out[key]["triangles"], out[key]["per_level"], flush=True)
-    json.dump(out, open(os.path.join(HERE, "big_configs.json"), "w"), indent=1, sort_keys=True)
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -65,7 +65,7 @@ def test_point_eval_bit_exact(ev, oracle, name, interpreter, monkeypatch):
     info = ev.scene_info()
     assert info["stack_depth"] == EXPECTED_STACK_DEPTH[name]
     # flat256 / grouped256 (built-in brushes, hundreds of objects) get the tile-culling kernels by default
-    auto = 3 if name in SPECIALISED else (4 if name in ("flat256", "grouped256") else 1)
+    auto = 3 if name in SPECIALISED else (4 if name in ("flat256", "grouped256", "smooth256") else 1)
     want_variant = {"auto": auto, "stack": 1, "generic": 0}[interpreter]
     assert info["interpreter"] == want_variant
     osc = oracle.Scene.from_dir(scene_dir(name))
@@ -97,13 +97,13 @@ def test_builtin_bank_equals_jit_bank(ev, oracle):
     assert np.array_equal(bits(a), bits(b))
 
 
-@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table", "const_table", "smooth_blobs", "flat256", "grouped256"])
+@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table", "const_table", "smooth_blobs", "flat256", "grouped256", "smooth256"])
 def test_lattice_sweep_bit_exact(ev, oracle, name):
     load(ev, name)
     osc = oracle.Scene.from_dir(scene_dir(name))
     center, diameter, _ = osc.estimate_bounding_box(10.0)
     res = 48  # not a power of two: exercises the x/w division path
-    if name in ("flat256", "grouped256"):  # hundreds of objects: keep the oracle's share short; culling kernels on the GPU
+    if name in ("flat256", "grouped256", "smooth256"):  # hundreds of objects: keep the oracle's share short; culling kernels on the GPU
         assert ev.scene_info()["interpreter"] == 4
         for r in (24, 32):
             gs, gn = ev.eval_lattice(center, diameter[0], r)
