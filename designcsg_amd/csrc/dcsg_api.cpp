@@ -225,7 +225,7 @@ bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std:
     if (p.needs_jit) {
         if (builtin_only) p.cl = builtin_scene_cl();
         p.null0 = builtin_only || scene_cl_null_brush_is_const(p.cl);
-        p.extra = specialised_source(s, p.null0, p.specialise);
+        p.extra = specialised_source(s, p.null0, p.specialise, builtin_only && !getenv("DCSG_NO_SIMPLIFY"));
     }
     return true;
 }
@@ -282,6 +282,9 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
 {
     if (res < 1 || z0 < 0 || z1 > res + 1 || z0 > z1) return fail(c, DCSG_ERR_INVALID, "bad lattice range");
     if (!d_sdf && !d_nrm) return 0;
+    for (int k = 0; k < 3; k++)  // lattice coordinates stay finite (the specialised kernels rely on it)
+        if (!(std::fabs(center[k]) <= 1e29f) || !(std::fabs(diam[k]) <= 1e29f))
+            return fail(c, DCSG_ERR_INVALID, "lattice box is not finite");
     const uint64_t n1 = (uint64_t)res + 1;
     const uint64_t total = (uint64_t)(z1 - z0) * n1 * n1;
     if (total >= 0xffffff00ull)
@@ -568,6 +571,7 @@ int dcsg_estimate_bounding_box(dcsg_ctx* c, float bb_half, float center[3], floa
     int r = need_scene(c);
     if (r) return r;
     const int R = 256;
+    if (!(std::fabs(bb_half) <= 1e29f)) return fail(c, DCSG_ERR_INVALID, "boundingBoxHalfDiameter is not finite");
     volatile float cd = (float)bb_half / R;  // cube_diameter
     volatile float half_neg = -cd / 2;       // v3f(-cube_diameter / 2)
     double bb_eps = (double)((float)bb_half / R) * 1.0;  // BB_EPSILON

@@ -310,7 +310,7 @@ extern "C" int dcsg_jit_prebuild(const char* scene_cl, char* log_out, size_t log
     std::string hsaco, log;
     bool cached = false;
     dcsg::Scene none;
-    bool ok = dcsg::jit_scene_module(scene_cl ? scene_cl : "", dcsg::specialised_source(none, false, false), hsaco, log,
+    bool ok = dcsg::jit_scene_module(scene_cl ? scene_cl : "", dcsg::specialised_source(none, false, false, false), hsaco, log,
                                      &cached);
     if (from_cache) *from_cache = cached ? 1 : 0;
     if (log_out && log_cap) {

@@ -122,6 +122,9 @@ typedef float dcsg_cl_float16 __attribute__((ext_vector_type(16)));
 extern "C" __device__ dcsg_cl_float16 dcsg_spec_eval14(dcsg_cl_float16 px, dcsg_cl_float16 py, dcsg_cl_float16 pz);
 extern "C" __device__ dcsg_cl_float8 dcsg_spec_eval7(dcsg_cl_float8 px, dcsg_cl_float8 py, dcsg_cl_float8 pz);
 extern "C" __device__ float dcsg_spec_eval1(float x, float y, float z);
+// dcsg_spec_eval1 with every term of every transform written out: valid for any input (the three above may
+// leave out terms with a zero coefficient, which is exact for finite coordinates only -- specialise.cpp)
+extern "C" __device__ float dcsg_spec_eval1x(float x, float y, float z);
 #define DCSG_HAVE_SPEC 1
 #else
 // OpenCL max(gentype x, gentype y): y if x < y, otherwise x
@@ -796,36 +799,37 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
 #endif
 
 #ifdef DCSG_HAVE_SPEC
-// Out-of-line copy for waves that hold a -0.0 coordinate (exact "+ 0.0f" stencil, no shared values).
-__device__ __noinline__ dcsg_cl_float8 dcsg_spec_eval7_exact(dcsg_cl_float8 px, dcsg_cl_float8 py, dcsg_cl_float8 pz)
-{
-    return dcsg_spec_eval7(px, py, pz);
-}
+// Out-of-line exact evaluation for the rare waves that hold a coordinate the fast specialised code must not see:
+// -0.0 (the stencil's "+ 0.0f" changes it) or a non-finite / huge value (zero-coefficient terms are not zero then).
+__device__ __noinline__ float dcsg_spec_exact(float x, float y, float z) { return dcsg_spec_eval1x(x, y, z); }
+__device__ __forceinline__ bool dcsg_spec_odd(float v) { return !(__builtin_fabsf(v) <= 1e30f) || dcsg_is_neg_zero(v); }
 
 // dcsg_stencil for the specialised scene module (K = -1 in the kernel bodies below).
 __device__ __forceinline__ void dcsg_stencil_spec(float x, float y, float z, bool want_sdf, bool want_normal, float& sdf,
                                                   float& nx, float& ny, float& nz)
 {
+    const bool odd = dcsg_spec_odd(x) || dcsg_spec_odd(y) || dcsg_spec_odd(z);
+    const float e = (float)K2_NORMAL_EPSILON;
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
+        const float zero = 0.0f;  // v+dx adds +0.0 on the other axes, v-dx subtracts it (k2.cl:167-173)
+        if (want_sdf || !want_normal) sdf = dcsg_spec_exact(x, y, z);
+        if (want_normal) {
+            float Dx = dcsg_spec_exact(x + e, y + zero, z + zero) - dcsg_spec_exact(x - e, y - zero, z - zero);
+            float Dy = dcsg_spec_exact(x + zero, y + e, z + zero) - dcsg_spec_exact(x - zero, y - e, z - zero);
+            float Dz = dcsg_spec_exact(x + zero, y + zero, z + e) - dcsg_spec_exact(x - zero, y - zero, z - e);
+            dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
+        }
+        return;
+    }
     if (!want_normal) {
         sdf = dcsg_spec_eval1(x, y, z);
         return;
     }
-    const float e = (float)K2_NORMAL_EPSILON;
     float xp = x + e, xm = x - e, yp = y + e, ym = y - e, zp = z + e, zm = z - e;
-    bool nzero = dcsg_is_neg_zero(x) || dcsg_is_neg_zero(y) || dcsg_is_neg_zero(z);
-    dcsg_cl_float8 o;
-    if (__builtin_amdgcn_ballot_w64(nzero) != 0ull) {
-        const float zero = 0.0f;  // v+dx adds +0.0 on the other axes, v-dx subtracts it (k2.cl:167-173)
-        dcsg_cl_float8 px = {x, xp, xm, x + zero, x - zero, x + zero, x - zero, 0.0f};
-        dcsg_cl_float8 py = {y, y + zero, y - zero, yp, ym, y + zero, y - zero, 0.0f};
-        dcsg_cl_float8 pz = {z, z + zero, z - zero, z + zero, z - zero, zp, zm, 0.0f};
-        o = dcsg_spec_eval7_exact(px, py, pz);
-    } else {
-        dcsg_cl_float8 px = {x, xp, xm, x, x, x, x, 0.0f};
-        dcsg_cl_float8 py = {y, y, y, yp, ym, y, y, 0.0f};
-        dcsg_cl_float8 pz = {z, z, z, z, z, zp, zm, 0.0f};
-        o = dcsg_spec_eval7(px, py, pz);
-    }
+    dcsg_cl_float8 px = {x, xp, xm, x, x, x, x, 0.0f};
+    dcsg_cl_float8 py = {y, y, y, yp, ym, y, y, 0.0f};
+    dcsg_cl_float8 pz = {z, z, z, z, z, zp, zm, 0.0f};
+    dcsg_cl_float8 o = dcsg_spec_eval7(px, py, pz);
     sdf = o[0];
     dcsg_finish_normal(o[1] - o[2], o[3] - o[4], o[5] - o[6], nx, ny, nz);
 }

@@ -60,7 +60,8 @@ bool parse_lookup_table(const char* text, std::vector<uint8_t>& table, int& tota
 float angle_threshold_to_q_star(float threshold);
 
 // csrc/specialise.cpp
-std::string specialised_source(const Scene& s, bool null_brush_const, bool enable);
+// simplify: the scene uses only the five standard brushes (see specialise.cpp for what that licenses)
+std::string specialised_source(const Scene& s, bool null_brush_const, bool enable, bool simplify);
 const char* builtin_scene_cl();
 
 uint64_t fnv1a64(const void* data, size_t n, uint64_t seed);

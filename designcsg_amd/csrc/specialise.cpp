@@ -21,7 +21,7 @@ static std::string hexf(float f)
     return buf;
 }
 
-static void emit_function(const Scene& s, bool null_brush_const, int N, std::string& out)
+static void emit_function(const Scene& s, bool null_brush_const, int N, bool simplify, const char* name1, std::string& out)
 {
     enum {
         PUSH = 32, ACC_MIN = 33, ACC_MAX = 34, ACC_NEGMAX = 35, POP_MIN = 36, POP_MAX = 37, POP_NEGMAX = 38, EXPORT_TOP = 39,
@@ -39,7 +39,7 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, std::str
     else if (N == 7)
         out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){\n";
     else
-        out += "float dcsg_spec_eval1(float x, float y, float z){\n";
+        out += std::string("float ") + name1 + "(float x, float y, float z){\n";
     auto X = [&](int k) { return N > 1 ? std::string("px.s") + hexdigit[k] : std::string("x"); };
     auto Y = [&](int k) { return N > 1 ? std::string("py.s") + hexdigit[k] : std::string("y"); };
     auto Z = [&](int k) { return N > 1 ? std::string("pz.s") + hexdigit[k] : std::string("z"); };
@@ -79,12 +79,38 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, std::str
                 P("    const float rx=%s, ry=%s, rz=%s;\n", hexf(r[0]).c_str(), hexf(r[1]).c_str(), hexf(r[2]).c_str());
                 P("    const float ux=%s, uy=%s, uz=%s;\n", hexf(u[0]).c_str(), hexf(u[1]).c_str(), hexf(u[2]).c_str());
                 P("    const float fx=%s, fy=%s, fz=%s;\n", hexf(f[0]).c_str(), hexf(f[1]).c_str(), hexf(f[2]).c_str());
+                // `simplify` (scenes made of the five standard brushes only): terms whose coefficient is exactly zero are
+                // left out, "* 1.0f" and "- 0.0f" are dropped.  For finite coordinates (|v| <= 1e30, guaranteed by the
+                // callers; anything else takes dcsg_spec_eval1x) such a product is +-0 and adding it changes nothing but,
+                // possibly, the sign of a zero sum -- which no standard brush can see (squares, fabs).  Same bits out.
+                auto finite_small = [](float v) { return v - v == 0.0f && v <= 1e30f && v >= -1e30f; };
+                bool simp = simplify;
+                for (int q = 0; q < 3; q++) simp = simp && finite_small(o[q]) && finite_small(r[q]) && finite_small(u[q]) && finite_small(f[q]);
+                auto row = [&](int k, const float* c, const char* cn) {
+                    std::string e;
+                    const char* d[3] = {"dx", "dy", "dz"};
+                    const char* ax[3] = {"x", "y", "z"};
+                    for (int q = 0; q < 3; q++) {
+                        std::string t = std::string(d[q]) + std::to_string(k);
+                        if (simp && c[q] == 0.0f) continue;
+                        if (simp && c[q] == -1.0f) t = "(-" + t + ")";
+                        else if (!(simp && c[q] == 1.0f)) t += std::string("*") + cn + ax[q];
+                        e += e.empty() ? t : " + " + t;
+                    }
+                    return e.empty() ? std::string("0.0f") : e;
+                };
                 for (int k = 0; k < N; k++) {
-                    P("    const float dx%d = %s - ox, dy%d = %s - oy, dz%d = %s - oz;\n", k, X(k).c_str(), k, Y(k).c_str(), k,
-                      Z(k).c_str());
-                    P("    const float r%d = sdf_bank((float3)(dx%d*rx + dy%d*ry + dz%d*rz, dx%d*ux + dy%d*uy + dz%d*uz, "
-                      "dx%d*fx + dy%d*fy + dz%d*fz), (unsigned char)%d);\n",
-                      k, k, k, k, k, k, k, k, k, k, brush);
+                    const std::string p3[3] = {X(k), Y(k), Z(k)};
+                    const char* d[3] = {"dx", "dy", "dz"};
+                    const char* on[3] = {"ox", "oy", "oz"};
+                    out += "    const float ";
+                    for (int q = 0; q < 3; q++) {
+                        out += std::string(d[q]) + std::to_string(k) + " = " + p3[q];
+                        if (!(simp && o[q] == 0.0f)) out += std::string(" - ") + on[q];
+                        out += q < 2 ? ", " : ";\n";
+                    }
+                    P("    const float r%d = sdf_bank((float3)(%s, %s, %s), (unsigned char)%d);\n", k, row(k, r, "r").c_str(),
+                      row(k, u, "u").c_str(), row(k, f, "f").c_str(), brush);
                 }
             }
             for (int k = 0; k < N; k++) {
@@ -123,18 +149,20 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, std::str
 // OpenCL C for dcsg_spec_eval7 / dcsg_spec_eval1.  With `enable` false (or a program that is not
 // stack-disciplined) it emits stubs, which only satisfy the linker: the host never selects the
 // specialised kernels for such a scene.
-std::string specialised_source(const Scene& s, bool null_brush_const, bool enable)
+std::string specialised_source(const Scene& s, bool null_brush_const, bool enable, bool simplify)
 {
     std::string out = "\n/* ---- generated by csrc/specialise.cpp ---- */\n";
     if (!enable || s.n_stack_prog == 0) {
         out += "float16 dcsg_spec_eval14(float16 px, float16 py, float16 pz){ return (float16)(0.0f); }\n";
         out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){ return (float8)(0.0f); }\n";
         out += "float dcsg_spec_eval1(float x, float y, float z){ return 0.0f; }\n";
+        out += "float dcsg_spec_eval1x(float x, float y, float z){ return 0.0f; }\n";
         return out;
     }
-    emit_function(s, null_brush_const, 14, out);
-    emit_function(s, null_brush_const, 7, out);
-    emit_function(s, null_brush_const, 1, out);
+    emit_function(s, null_brush_const, 14, simplify, "", out);
+    emit_function(s, null_brush_const, 7, simplify, "", out);
+    emit_function(s, null_brush_const, 1, simplify, "dcsg_spec_eval1", out);
+    emit_function(s, null_brush_const, 1, false, "dcsg_spec_eval1x", out);  // every term written out: any input
     return out;
 }
 

@@ -80,6 +80,19 @@ def test_point_eval_bit_exact(ev, oracle, name, interpreter, monkeypatch):
     want_s, want_n = osc.eval_sdf(pts), osc.eval_normal(pts)
     assert np.array_equal(bits(got_s), bits(want_s))
     assert np.array_equal(bits(got_n), bits(want_n))
+    # coordinates the fast specialised code must hand to its exact path: non-finite, huge, -0.0 (each mixed with
+    # ordinary points in the same wave); NaN results compare as NaN, everything else bit for bit
+    odd = rng.uniform(-2.0, 2.0, (256, 3)).astype(np.float32)
+    odd[3] = (np.inf, 0.1, 0.2)
+    odd[17] = (0.3, -np.inf, 0.0)
+    odd[70] = (np.nan, 0.0, 0.0)
+    odd[90] = (1e35, 0.0, -1e35)
+    odd[131] = (-0.0, 0.25, 0.5)
+    odd[200] = (3e38, 3e38, -3e38)
+    with np.errstate(all="ignore"):
+        for got, want in ((ev.eval_sdf_at_points(odd), osc.eval_sdf(odd)), (ev.eval_normal_at_points(odd), osc.eval_normal(odd))):
+            both_nan = np.isnan(got) & np.isnan(want)
+            assert np.array_equal(np.where(both_nan, 0, bits(got)), np.where(both_nan, 0, bits(want)))
 
 
 def test_builtin_bank_equals_jit_bank(ev, oracle):
