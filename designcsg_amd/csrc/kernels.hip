@@ -804,11 +804,14 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
 __device__ __noinline__ float dcsg_spec_exact(float x, float y, float z) { return dcsg_spec_eval1x(x, y, z); }
 __device__ __forceinline__ bool dcsg_spec_odd(float v) { return !(__builtin_fabsf(v) <= 1e30f) || dcsg_is_neg_zero(v); }
 
-// dcsg_stencil for the specialised scene module (K = -1 in the kernel bodies below).
+// dcsg_stencil for the specialised scene module (K = -1 in the kernel bodies below).  LATTICE: the coordinates are
+// lattice positions of a box the host has checked to be finite, so only -0.0 can be odd, and only for the stencil.
+template <bool LATTICE = false>
 __device__ __forceinline__ void dcsg_stencil_spec(float x, float y, float z, bool want_sdf, bool want_normal, float& sdf,
                                                   float& nx, float& ny, float& nz)
 {
-    const bool odd = dcsg_spec_odd(x) || dcsg_spec_odd(y) || dcsg_spec_odd(z);
+    const bool odd = LATTICE ? (want_normal && (dcsg_is_neg_zero(x) || dcsg_is_neg_zero(y) || dcsg_is_neg_zero(z)))
+                             : (dcsg_spec_odd(x) || dcsg_spec_odd(y) || dcsg_spec_odd(z));
     const float e = (float)K2_NORMAL_EPSILON;
     if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
         const float zero = 0.0f;  // v+dx adds +0.0 on the other axes, v-dx subtracts it (k2.cl:167-173)
@@ -893,7 +896,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             if (nrm_out) dcsg_get_normal(s, x, y, z, nx, ny, nz);
 #ifdef DCSG_HAVE_SPEC
         } else if (K < 0) {
-            dcsg_stencil_spec(x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
+            dcsg_stencil_spec<true>(x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
 #endif
         } else {
             dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
@@ -958,8 +961,8 @@ dcsg_sweep_sp2(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0
         bool nzero = dcsg_is_neg_zero(x) || dcsg_is_neg_zero(y) || dcsg_is_neg_zero(za) || dcsg_is_neg_zero(zb);
         if (!nrm_out || __builtin_amdgcn_ballot_w64(nzero) != 0ull) {
             // SDF-only sweeps and waves with a -0.0 coordinate: the one-point paths
-            dcsg_stencil_spec(x, y, za, sdf_out != nullptr, nrm_out != nullptr, sd[0], n[0][0], n[0][1], n[0][2]);
-            if (second) dcsg_stencil_spec(x, y, zb, sdf_out != nullptr, nrm_out != nullptr, sd[1], n[1][0], n[1][1], n[1][2]);
+            dcsg_stencil_spec<true>(x, y, za, sdf_out != nullptr, nrm_out != nullptr, sd[0], n[0][0], n[0][1], n[0][2]);
+            if (second) dcsg_stencil_spec<true>(x, y, zb, sdf_out != nullptr, nrm_out != nullptr, sd[1], n[1][0], n[1][1], n[1][2]);
         } else {
             float xp = x + e, xm = x - e, yp = y + e, ym = y - e;
             dcsg_cl_float16 px = {x, xp, xm, x, x, x, x, x, xp, xm, x, x, x, x, 0.0f, 0.0f};
