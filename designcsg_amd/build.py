@@ -63,6 +63,10 @@ def build(verbose=False, prebuild_scenes=True):
     bc = os.path.join(OUT, "dcsg_kernels_extern.bc")
     if _newer(bc, dev_deps):
         _run([HIPCC] + DEVICE_FLAGS + ["-fgpu-rdc", "-emit-llvm", "-DDCSG_EXTERN_BANK", "-c", kernels, "-o", bc])
+        # every cached scene module was linked against the old kernel bitcode (its hash is part of the key):
+        # drop them so that stale code objects do not pile up (the fixture scenes are rebuilt below)
+        for f in glob.glob(os.path.join(OUT, "jitcache", "*.hsaco")):
+            os.remove(f)
 
     _embed_cl()
     host_src = [os.path.join(CSRC, f) for f in ("dcsg_api.cpp", "scene.cpp", "jit.cpp", "specialise.cpp")]

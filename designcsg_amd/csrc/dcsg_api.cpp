@@ -893,6 +893,16 @@ bool pwrite_all(int fd, const unsigned char* buf, size_t bytes, off_t off)
     return true;
 }
 
+// An existing file is overwritten in place and cut to its new length at the end: truncating first makes the kernel
+// free and re-allocate every page-cache page of the old file, which costs more than writing the bytes (C4: 36 ms
+// against 12 ms for the 136 MB .ply).
+int open_for_overwrite(const char* path) { return open(path, O_WRONLY | O_CREAT, 0644); }
+bool finish_file(int fd, off_t size, bool ok)
+{
+    if (ftruncate(fd, size) != 0) ok = false;
+    return close(fd) == 0 && ok;
+}
+
 unsigned writer_threads()
 {
     const char* e = getenv("DCSG_WRITER_THREADS");
@@ -909,7 +919,7 @@ extern "C" {
 int dcsg_write_stl(const char* path, const float* tris, uint64_t n)
 {
     if (!path || (n && !tris)) return DCSG_ERR_INVALID;
-    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    int fd = open_for_overwrite(path);
     if (fd < 0) return DCSG_ERR_IO;
     unsigned char head[84];
     memset(head, 0, sizeof(head));
@@ -932,7 +942,7 @@ int dcsg_write_stl(const char* path, const float* tris, uint64_t n)
         }
         return true;
     });
-    return (close(fd) == 0 && ok) ? 0 : DCSG_ERR_IO;
+    return finish_file(fd, (off_t)(84 + n * 50), ok) ? 0 : DCSG_ERR_IO;
 }
 
 // writeTrianglesToPLY, utils.hpp:106-154 via happly.h:1998-2039 (header), 1538-1570 (double x,y,z),
@@ -947,7 +957,7 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
                       "element vertex %llu\nproperty double x\nproperty double y\nproperty double z\n"
                       "element face %llu\nproperty list uchar uint vertex_indices\nend_header\n",
                       (unsigned long long)(n * 3), (unsigned long long)n);
-    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    int fd = open_for_overwrite(path);
     if (fd < 0) return DCSG_ERR_IO;
     bool ok = pwrite_all(fd, (const unsigned char*)header, (size_t)hl, 0);
     const off_t verts_at = hl, faces_at = hl + (off_t)(n * 72);
@@ -972,7 +982,7 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
         }
         return true;
     });
-    return (close(fd) == 0 && ok) ? 0 : DCSG_ERR_IO;
+    return finish_file(fd, (off_t)hl + (off_t)(n * 85), ok) ? 0 : DCSG_ERR_IO;
 }
 
 // ---- opt-in writers beyond the reference's -----------------------------------------------
@@ -981,7 +991,7 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
 int dcsg_write_stl_normals(const char* path, const float* tris, uint64_t n)
 {
     if (!path || (n && !tris)) return DCSG_ERR_INVALID;
-    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    int fd = open_for_overwrite(path);
     if (fd < 0) return DCSG_ERR_IO;
     unsigned char head[84];
     memset(head, 0, sizeof(head));
@@ -1013,7 +1023,7 @@ int dcsg_write_stl_normals(const char* path, const float* tris, uint64_t n)
         }
         return true;
     });
-    return (close(fd) == 0 && ok) ? 0 : DCSG_ERR_IO;
+    return finish_file(fd, (off_t)(84 + n * 50), ok) ? 0 : DCSG_ERR_IO;
 }
 
 // Indexed PLY: every distinct vertex position (bit pattern) once, in order of first appearance, as float
@@ -1057,7 +1067,7 @@ int dcsg_write_ply_indexed(const char* path, const float* tris, uint64_t n, uint
                       "element vertex %llu\nproperty float x\nproperty float y\nproperty float z\n"
                       "element face %llu\nproperty list uchar uint vertex_indices\nend_header\n",
                       (unsigned long long)nv, (unsigned long long)n);
-    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    int fd = open_for_overwrite(path);
     if (fd < 0) return DCSG_ERR_IO;
     bool ok = pwrite_all(fd, (const unsigned char*)header, (size_t)hl, 0);
     ok = ok && pwrite_all(fd, (const unsigned char*)verts.data(), (size_t)nv * 12, hl);
@@ -1077,7 +1087,7 @@ int dcsg_write_ply_indexed(const char* path, const float* tris, uint64_t n, uint
         }
         return true;
     });
-    return (close(fd) == 0 && ok) ? 0 : DCSG_ERR_IO;
+    return finish_file(fd, (off_t)hl + (off_t)(nv * 12 + n * 13), ok) ? 0 : DCSG_ERR_IO;
 }
 
 int dcsg_debug_sqrt_device(dcsg_ctx* c, const float* d_in, size_t n, float* d_out, void* stream)

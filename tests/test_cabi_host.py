@@ -130,7 +130,7 @@ def test_opt_in_writers(built_lib, tmp_path):
 def test_writers_byte_identical_to_oracle(built_lib, oracle, tmp_path):
     from designcsg_amd.evaluator import write_ply, write_stl
     rng = np.random.default_rng(0)
-    for n in (0, 1, 1000):
+    for n in (0, 1, 1000, 3, 0):   # the same paths again and again: files are overwritten in place, then cut
         tris = rng.normal(size=(n, 3, 3)).astype(np.float32)
         write_stl(tmp_path / "a.stl", tris)
         write_ply(tmp_path / "a.ply", tris)
