@@ -71,6 +71,7 @@ PROTOTYPES = {
     "dcsg_triangles_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "dcsg_download_triangles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "dcsg_copy_triangles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "dcsg_render_preview": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dcsg_write_stl": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
     "dcsg_write_ply": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
     "dcsg_write_stl_normals": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),

@@ -57,6 +57,9 @@ struct dcsg_ctx {
     size_t max_lds = 65536;
     hipStream_t stream = nullptr;
     hipModule_t builtin_mod = nullptr, scene_mod = nullptr;
+    hipModule_t preview_mod = nullptr;  // scene.cl as given + kernels, built on the first dcsg_render_preview of a scene
+    hipFunction_t preview_fn = nullptr;
+    std::string scene_cl_text;
     Kernels kb, ks;       // built-in bank / scene module
     Kernels* k = nullptr;  // active
     bool scene_loaded = false, jit = false, specialised = false;
@@ -395,11 +398,50 @@ void dcsg_destroy(dcsg_ctx* c)
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->scene_mod) hipModuleUnload(c->scene_mod);
+    if (c->preview_mod) hipModuleUnload(c->preview_mod);
     if (c->builtin_mod) hipModuleUnload(c->builtin_mod);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
+}
+
+// Kernel k1 (k1.cl:479-578; DrawPane.cpp:373-470 is its host side): the 640 x 480 preview image of the loaded scene.
+// The materials are OpenCL C text of scene.cl, so the image comes from a module built from that text (cached on
+// disk like every scene module); a scene loaded without scene.cl gets the standard brushes and materials.
+int dcsg_render_preview(dcsg_ctx* c, const float campos[3], const float right[3], const float up[3], const float forward[3],
+                        unsigned char* rgb_out)
+{
+    int r = need_scene(c);
+    if (r) return r;
+    if (!campos || !right || !up || !forward || !rgb_out) return fail(c, DCSG_ERR_INVALID, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->preview_fn) {
+        std::string text = c->scene_cl_text.empty() ? std::string(builtin_scene_cl()) : c->scene_cl_text;
+        std::string hsaco, log;
+        Scene none;
+        if (!jit_scene_module(text, specialised_source(none, false, false, false), hsaco, log, nullptr))
+            return fail(c, DCSG_ERR_BUILD, "Error when building preview program:\n" + log);
+        HIPCHK(c, hipModuleLoadData(&c->preview_mod, hsaco.data()));
+        hipFunction_t set_ad = nullptr;
+        HIPCHK(c, hipModuleGetFunction(&c->preview_fn, c->preview_mod, "dcsg_preview"));
+        HIPCHK(c, hipModuleGetFunction(&set_ad, c->preview_mod, "dcsg_set_arbitrary_data"));
+        void* ad = c->d_ad.p;
+        void* args[] = {&ad};
+        if ((r = launch(c, set_ad, 1, 64, 0, c->stream, args))) return r;
+    }
+    const size_t bytes = 640 * 480 * 3;
+    if ((r = ensure(c, c->d_out, bytes))) return r;
+    DcsgCamera cam;
+    for (int k = 0; k < 3; k++) cam.o[k] = campos[k], cam.r[k] = right[k], cam.u[k] = up[k], cam.f[k] = forward[k];
+    const void* blob = c->d_blob.p;
+    int nv = c->scene.blob_vec4(), n_obj = c->scene.n_objects;
+    void* out = c->d_out.p;
+    void* args[] = {(void*)&blob, &nv, &cam, &n_obj, &out};
+    if ((r = launch(c, c->preview_fn, 640 * 480 / DCSG_BLOCK, DCSG_BLOCK, c->scene.lds_bytes(), c->stream, args))) return r;
+    HIPCHK(c, hipMemcpyAsync(rgb_out, c->d_out.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int dcsg_set_lookup_table(dcsg_ctx* c, const char* txt)
@@ -495,6 +537,13 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     }
     c->scene_loaded = true;
     c->n_tris = 0;
+    c->scene_cl_text = scene_cl ? scene_cl : "";
+    if (c->preview_mod) {  // belongs to the previous scene
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipModuleUnload(c->preview_mod));
+        c->preview_mod = nullptr;
+        c->preview_fn = nullptr;
+    }
     std::fill(c->ad_host.begin(), c->ad_host.end(), 0.0f);
     return dcsg_set_arbitrary_data(c, ad, ad ? n_ad : 0);
 }

@@ -30,4 +30,8 @@ struct DcsgMeshParams {
                              // leaves emit triangles only where their lowest plane is in [z_own_lo, z_own_hi)
 };
 
+struct DcsgCamera {  // kernel k1's campos / right / up / forward buffers (k1.cl:481-486)
+    float o[3], r[3], u[3], f[3];
+};
+
 #endif

@@ -107,6 +107,9 @@ __device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v)
 typedef float dcsg_cl_float3 __attribute__((ext_vector_type(3)));
 extern "C" __device__ float sdf_bank(dcsg_cl_float3 v, unsigned char shape_id);  // generated scene.cl
 extern "C" __device__ void dcsg_scene_set_ad(__attribute__((address_space(1))) float* p);  // scene_prelude.cl
+// preview only: the scene's materials and the camera basis they may read (scene_epilogue.cl)
+extern "C" __device__ dcsg_cl_float3 shader_bank(dcsg_cl_float3 gv, dcsg_cl_float3 lv, dcsg_cl_float3 n, unsigned char material_id);
+extern "C" __device__ void dcsg_scene_set_camera(dcsg_cl_float3 r, dcsg_cl_float3 u, dcsg_cl_float3 f);
 __device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_id)
 {
     dcsg_cl_float3 v = {x, y, z};
@@ -164,7 +167,7 @@ __device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_
 // {n_stack_steps, stack_depth, n_items, 0}; then the register program, the stack program, the culling
 // items, the objects:
 // steps {opcode,left,right,dest}; 4 x float4 per object:
-// {pos.xyz, shape_id bits}, {right.xyz,0}, {up.xyz,0}, {forward.xyz,0}.
+// {pos.xyz, brush id | material id << 8}, {right.xyz, Lipschitz bound}, {up.xyz,0}, {forward.xyz,0}.
 // After the blob: the interpreter stack, slot-major (slot*DCSG_BLOCK + tid), so
 // every access is one conflict-free ds_read/ds_write_b32.
 // ---------------------------------------------------------------------------
@@ -1765,6 +1768,121 @@ dcsg_test_sqrt(const float* __restrict__ in, float* __restrict__ out, unsigned i
 {
     for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < n; i += gridDim.x * DCSG_BLOCK) out[i] = dcsg_sqrt(in[i]);
 }
+
+#ifdef DCSG_EXTERN_BANK
+// ---------------------------------------------------------------------------
+// Preview: kernel k1 (k1.cl:479-578) -- sphere tracing of the scene plus the three axis markers into a 640 x 480
+// RGB image, one thread per pixel, the build procedure through the generic interpreter.  Scene modules only (the
+// materials are OpenCL C text of scene.cl).  Arithmetic as the kernel text states it: float, left to right,
+// comparisons against the double literals in double.  Checked against oracle_render_preview.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dcsg_axes_cylinder(float r, float h, float half_length, float radius)
+{
+    float a = __builtin_fabsf(h) - half_length, b = r - radius;  // axes_cylinderSDF, k1.cl:46-48
+    return a > b ? a : b;
+}
+
+// primary_sdf of k1.cl:121-283: k2's build procedure, then the axis markers
+__device__ __noinline__ float dcsg_k1_sdf(const SceneLds& s, float x, float y, float z)
+{
+    float ev = dcsg_primary_sdf(s, x, y, z);
+    float vx = x / 5.0f, vy = y / 5.0f, vz = z / 5.0f;  // k1.cl:239
+    const float radius = (float)0.015;                  // AXES_RADIUS
+    float c;
+    c = dcsg_axes_cylinder(dcsg_sqrt(vy * vy + vz * vz), vx - 0.5f, 0.5f, radius);
+    ev = ev < c ? ev : c;
+    c = dcsg_axes_cylinder(dcsg_sqrt(vx * vx + vz * vz), vy - 0.5f, 0.5f, radius);
+    ev = ev < c ? ev : c;
+    c = dcsg_axes_cylinder(dcsg_sqrt(vx * vx + vy * vy), vz - 0.5f, 0.5f, radius);
+    ev = ev < c ? ev : c;
+    return ev;
+}
+
+__device__ __forceinline__ unsigned char dcsg_colour_byte(float c)
+{
+    int v = (int)(255.0 * (double)c);  // RCOMP, k1.cl:8; v_cvt_i32_f64 saturates, NaN -> 0
+    return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_preview(const uint4* __restrict__ blob, int n_vec4, DcsgCamera cam, int n_objects, unsigned char* __restrict__ out)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    const int tid = (int)(blockIdx.x * DCSG_BLOCK + threadIdx.x);
+    if (tid >= 640 * 480) return;
+    {
+        dcsg_cl_float3 r = {cam.r[0], cam.r[1], cam.r[2]}, u = {cam.u[0], cam.u[1], cam.u[2]}, f = {cam.f[0], cam.f[1], cam.f[2]};
+        dcsg_scene_set_camera(r, u, f);  // rgt_g = rgt; ... every work-item, k1.cl:521-523
+    }
+    const int ix = tid % 640, iy = tid / 640;
+    const float uvx = (float)(ix - 320) / 320.0f, uvy = -(float)(iy - 240) / 320.0f;  // k1.cl:515
+    const float ox = cam.o[0] * cam.r[0] + cam.o[1] * cam.r[1] + cam.o[2] * cam.r[2];
+    const float oy = cam.o[0] * cam.u[0] + cam.o[1] * cam.u[1] + cam.o[2] * cam.u[2];
+    const float oz = cam.o[0] * cam.f[0] + cam.o[1] * cam.f[1] + cam.o[2] * cam.f[2];
+    const float rx = uvx * cam.r[0] + uvy * cam.r[1] + 1.0f * cam.r[2];  // r = (uv.x, uv.y, IFOV)
+    const float ry = uvx * cam.u[0] + uvy * cam.u[1] + 1.0f * cam.u[2];
+    const float rz = uvx * cam.f[0] + uvy * cam.f[1] + 1.0f * cam.f[2];
+    // march, k1.cl:419-470
+    float d = 0.0f, vx = ox, vy = oy, vz = oz, hit = -1.0f;
+    for (int i = 0; i < 512; i++) {
+        float st = (float)((double)dcsg_k1_sdf(s, vx, vy, vz) * 0.85);
+        if ((double)st < 0.005) {
+            hit = d;
+            break;
+        }
+        vx = vx + st * rx;
+        vy = vy + st * ry;
+        vz = vz + st * rz;
+        d = d + st;
+        if ((double)d > 64.0) break;
+    }
+    float cr = 1.0f, cg = 1.0f, cb = 1.0f;
+    if ((double)hit > 0.0) {
+        const float px = ox + hit * rx, py = oy + hit * ry, pz = oz + hit * rz;
+        const float e = (float)K2_NORMAL_EPSILON, zero = 0.0f;
+        float Dx = dcsg_k1_sdf(s, px + e, py + zero, pz + zero) - dcsg_k1_sdf(s, px - e, py - zero, pz - zero);
+        float Dy = dcsg_k1_sdf(s, px + zero, py + e, pz + zero) - dcsg_k1_sdf(s, px - zero, py - e, pz - zero);
+        float Dz = dcsg_k1_sdf(s, px + zero, py + zero, pz + e) - dcsg_k1_sdf(s, px - zero, py - zero, pz - e);
+        float nx, ny, nz;
+        dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
+        // shade, k1.cl:285-379: the LAST object within 2*SDF_EPSILON supplies the material
+        int match = -1;
+        float ma = 0.0f, mb = 0.0f, mc = 0.0f;
+        for (int i = 0; i < n_objects; i++) {
+            float4 q0 = s.obj[4 * i + 0], q1 = s.obj[4 * i + 1], q2 = s.obj[4 * i + 2], q3 = s.obj[4 * i + 3];
+            float dx = px - q0.x, dy = py - q0.y, dz = pz - q0.z;
+            float A = dx * q1.x + dy * q1.y + dz * q1.z;
+            float B = dx * q2.x + dy * q2.y + dz * q2.z;
+            float C = dx * q3.x + dy * q3.y + dz * q3.z;
+            float sd = dcsg_bank(A, B, C, __float_as_int(q0.w) & 0xff);
+            if ((double)sd < 0.005 * 2.0) {
+                match = i;
+                ma = A, mb = B, mc = C;
+            }
+        }
+        if (match != -1) {
+            dcsg_cl_float3 gv = {px, py, pz}, lv = {ma, mb, mc}, n = {nx, ny, nz};
+            int material = (__float_as_int(s.obj[4 * match].w) >> 8) & 0xff;
+            dcsg_cl_float3 c = shader_bank(gv, lv, n, (unsigned char)material);
+            cr = c[0], cg = c[1], cb = c[2];
+        } else {
+            float ax = px / 5.0f, ay = py / 5.0f, az = pz / 5.0f;
+            const float radius = (float)0.025;
+            cr = (float)(239.0 / 255.0), cg = (float)(66.0 / 255.0), cb = 0.0f;  // "245/255" is an integer division
+            if ((double)dcsg_axes_cylinder(dcsg_sqrt(ay * ay + az * az), ax - 0.5f, 0.5f, radius) < 0.005 * 2.0) {
+                cr = 1.0f, cg = 0.0f, cb = 0.0f;
+            } else if ((double)dcsg_axes_cylinder(dcsg_sqrt(ax * ax + az * az), ay - 0.5f, 0.5f, radius) < 0.005 * 2.0) {
+                cr = 0.0f, cg = 1.0f, cb = 0.0f;
+            } else if ((double)dcsg_axes_cylinder(dcsg_sqrt(ax * ax + ay * ay), az - 0.5f, 0.5f, radius) < 0.005 * 2.0) {
+                cr = 0.0f, cg = 0.0f, cb = 1.0f;
+            }
+        }
+    }
+    out[tid * 3 + 0] = dcsg_colour_byte(cr);
+    out[tid * 3 + 1] = dcsg_colour_byte(cg);
+    out[tid * 3 + 2] = dcsg_colour_byte(cb);
+}
+#endif
 
 #ifdef DCSG_EXTERN_BANK
 // Points the scene module's program-scope `arbitrary_data` (k2.cl:41,251) at the uploaded table.

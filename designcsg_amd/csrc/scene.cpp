@@ -34,7 +34,7 @@ bool parse_scene(const char* scene_txt, const char* bp_txt, Scene& s, std::strin
             return false;
         }
         p = end;
-        (void)strtol(p, &end, 10);  // material id: not used by the export path
+        long material = strtol(p, &end, 10);  // material id: used by the preview only
         if (end == p) {
             err = "scene.txt: expected material id at object " + std::to_string(s.n_objects);
             return false;
@@ -50,6 +50,7 @@ bool parse_scene(const char* scene_txt, const char* bp_txt, Scene& s, std::strin
             p = end;
         }
         s.shape.push_back((uint8_t)brush);
+        s.material.push_back((uint8_t)material);
         for (int k = 0; k < 3; k++) {
             s.pos.push_back(v[k]);
             s.right.push_back(v[3 + k]);
@@ -471,7 +472,7 @@ void build_blob(Scene& s, bool null_brush_is_const)
         s.blob.push_back(f2u(s.pos[3 * i]));
         s.blob.push_back(f2u(s.pos[3 * i + 1]));
         s.blob.push_back(f2u(s.pos[3 * i + 2]));
-        s.blob.push_back((uint32_t)s.shape[i]);
+        s.blob.push_back((uint32_t)s.shape[i] | ((uint32_t)s.material[i] << 8));  // brush id, material id
         // Lipschitz bound of v -> (dot(v-o,right), dot(v-o,up), dot(v-o,forward)): the spectral norm of the matrix
         // with those rows is at most its Frobenius norm (rounded up); used by the tile culling only.
         double fro = 0;

@@ -14,6 +14,7 @@ namespace dcsg {
 struct Scene {
     int n_objects = 0, n_steps = 0, n_slots = 0;
     std::vector<uint8_t> shape;                // [n_objects]
+    std::vector<uint8_t> material;             // [n_objects] second column of scene.txt (preview only)
     std::vector<float> pos, right, up, fwd;    // [3*n_objects]
     std::vector<int32_t> steps;                // [4*n_steps] opcode,left,right,dest  (as in buildprocedure.txt)
     std::vector<int32_t> prog;                 // internal program: fused + slots renamed (optimise_program)

@@ -178,7 +178,14 @@ const char* builtin_scene_cl()
            "float sdf_bank(float3 v, unsigned char shape_id){\n"
            "  switch(shape_id){ case 0: return sd0(v); case 1: return sd1(v); case 2: return sd2(v);\n"
            "                    case 3: return sd3(v); case 4: return sd4(v); }\n"
-           "  return 0.0;\n}\n";
+           "  return 0.0;\n}\n"
+           // the two materials every scene starts with (scenecompiler.py:426-427), for the preview
+           "float3 shader0 (float3 gv, float3 lv, float3 n){ return fabs(n); }\n"
+           "float3 shader1 (float3 gv, float3 lv, float3 n){ float3 n_g = n.x*rgt_g+n.y*upp_g+n.z*fwd_g;\n"
+           "  float L = dot(n_g,(float3)(0.0,0.0,-1.0)); return (float3)(L,L,L); }\n"
+           "float3 shader_bank(float3 gv, float3 lv, float3 n, unsigned char material_id){\n"
+           "  switch(material_id){ case 0: return shader0(gv,lv,n); case 1: return shader1(gv,lv,n); }\n"
+           "  return (float3)(1.0, 1.0, 1.0);\n}\n";
 }
 
 }  // namespace dcsg

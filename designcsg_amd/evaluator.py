@@ -180,6 +180,14 @@ class Evaluator:
     def debug_sqrt_device(self, d_in, n, d_out, stream=0):
         self._ck(self._L.dcsg_debug_sqrt_device(self._h, C.c_void_p(d_in), n, C.c_void_p(d_out), C.c_void_p(stream or None)))
 
+    def render_preview(self, campos=(0.0, 0.0, -15.0), right=(1.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), forward=(0.0, 0.0, 1.0)):
+        """Kernel k1: the 640x480 preview of the loaded scene as a (480, 640, 3) uint8 array."""
+        v = [np.ascontiguousarray(a, dtype=np.float32) for a in (campos, right, up, forward)]
+        out = np.zeros((480, 640, 3), dtype=np.uint8)
+        self._ck(self._L.dcsg_render_preview(self._h, _fptr(v[0]), _fptr(v[1]), _fptr(v[2]), _fptr(v[3]),
+                                             out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def export(self, export_config_txt, stl_path=None, ply_path=None, dense_normals=False, indexed_ply=False,
                stl_normals=False):
         """MyFrame::OnExportInner end to end on this GPU.  indexed_ply / stl_normals select the opt-in writers

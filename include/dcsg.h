@@ -151,6 +151,12 @@ int dcsg_write_ply(const char* path, const float* triangles, uint64_t n_triangle
 int dcsg_write_stl_normals(const char* path, const float* triangles, uint64_t n_triangles);
 int dcsg_write_ply_indexed(const char* path, const float* triangles, uint64_t n_triangles, uint64_t* n_unique_vertices);
 
+/* Kernel k1 (k1.cl:479-578, host side DrawPane.cpp:373-470): the 640 x 480 preview image of the loaded scene by
+ * sphere tracing, RGB, 3 bytes per pixel, rows top to bottom, into rgb_out[640*480*3] (host memory).
+ * campos / right / up / forward are the four float[3] buffers the reference uploads per frame. */
+int dcsg_render_preview(dcsg_ctx* ctx, const float campos[3], const float right[3], const float up[3],
+                        const float forward[3], unsigned char* rgb_out);
+
 int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* out);
 /* MyFrame::OnExportInner (DesignCSG.cpp:638-790) end to end on one GPU: stage A, lattice sweep,
  * mesher, retopologize (identity), projection, both writers.

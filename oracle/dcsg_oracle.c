@@ -111,6 +111,7 @@ oracle_scene *oracle_scene_parse(const char *scene_txt, const char *buildprocedu
     oracle_scene *s = (oracle_scene *)calloc(1, sizeof(*s));
     int cap_o = count_lines(scene_txt), cap_s = count_lines(buildprocedure_txt);
     s->shape_id = (unsigned char *)calloc(cap_o + 1, 1);
+    s->material_id = (unsigned char *)calloc(cap_o + 1, 1);
     s->pos = (float *)calloc(3 * (cap_o + 1), sizeof(float));
     s->right = (float *)calloc(3 * (cap_o + 1), sizeof(float));
     s->up = (float *)calloc(3 * (cap_o + 1), sizeof(float));
@@ -125,7 +126,7 @@ oracle_scene *oracle_scene_parse(const char *scene_txt, const char *buildprocedu
         if (end == p)
             break;
         p = end;
-        (void)strtol(p, &end, 10); /* material id: irrelevant to export */
+        long material = strtol(p, &end, 10); /* material id: used by the preview only */
         p = end;
         float v[12];
         for (int k = 0; k < 12; k++) {
@@ -134,6 +135,7 @@ oracle_scene *oracle_scene_parse(const char *scene_txt, const char *buildprocedu
         }
         int i = s->n_objects++;
         s->shape_id[i] = (unsigned char)brush;
+        s->material_id[i] = (unsigned char)material;
         for (int k = 0; k < 3; k++) {
             s->pos[i * 3 + k] = v[k];
             s->right[i * 3 + k] = v[3 + k];
@@ -168,6 +170,7 @@ void oracle_scene_free(oracle_scene *s)
     if (!s)
         return;
     free(s->shape_id);
+    free(s->material_id);
     free(s->pos);
     free(s->right);
     free(s->up);
@@ -177,6 +180,14 @@ void oracle_scene_free(oracle_scene *s)
 }
 
 void oracle_scene_set_bank(oracle_scene *s, oracle_bank_fn bank) { s->bank = bank ? bank : oracle_builtin_bank; }
+
+void oracle_scene_set_shader(oracle_scene *s,
+                             void (*shader)(const float *, const float *, const float *, int, float *),
+                             void (*set_camera)(const float *, const float *, const float *))
+{
+    s->shader = shader;
+    s->set_camera = set_camera;
+}
 
 /* exportConfig.txt: 9 lines, std::stof / std::stoi positional, DesignCSG.cpp:827-835 */
 int oracle_parse_export_config(const char *text, oracle_export_config *c)
@@ -841,6 +852,176 @@ void oracle_gradient_descent(const oracle_scene *s, int steps, float *tris, size
 }
 
 void oracle_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------ */
+/* Preview: kernel k1 (k1.cl).  PARITY UNPINNED (see dcsg_oracle.h).       */
+
+/* axes_cylinderSDF, k1.cl:46-48 */
+static inline float axes_cylinder_sdf(float r, float h, float half_length, float radius)
+{
+    float a = fabsf(h) - half_length, b = r - radius;
+    return a > b ? a : b; /* T_max */
+}
+
+/* primary_sdf of k1.cl:121-283 = the build procedure (identical to k2.cl's) + the three axis markers */
+static float k1_primary_sdf(const oracle_scene *s, float x, float y, float z)
+{
+    float export_value = oracle_primary_sdf(s, x, y, z);
+    /* k1.cl:239: v/5.0 -- a double division narrowed by the float3 cast, equal to the float division */
+    float vx = x / 5.0f, vy = y / 5.0f, vz = z / 5.0f;
+    const float radius = (float)0.015; /* AXES_RADIUS */
+    float c;
+    c = axes_cylinder_sdf(sqrtf(vy * vy + vz * vz), vx - 0.5f, 0.5f, radius); /* k1.cl:243-250 */
+    export_value = export_value < c ? export_value : c;
+    c = axes_cylinder_sdf(sqrtf(vx * vx + vz * vz), vy - 0.5f, 0.5f, radius); /* k1.cl:253-260 */
+    export_value = export_value < c ? export_value : c;
+    c = axes_cylinder_sdf(sqrtf(vx * vx + vy * vy), vz - 0.5f, 0.5f, radius); /* k1.cl:264-271 */
+    export_value = export_value < c ? export_value : c;
+    return export_value;
+}
+
+/* get_normal of k1.cl:381-417: the stencil of k2.cl over k1's primary_sdf */
+static void k1_get_normal(const oracle_scene *s, float x, float y, float z, float out[3])
+{
+    const float e = (float)K2_NORMAL_EPSILON;
+    const float zero = (float)0.0;
+    float Dx = k1_primary_sdf(s, x + e, y + zero, z + zero) - k1_primary_sdf(s, x - e, y - zero, z - zero);
+    float Dy = k1_primary_sdf(s, x + zero, y + e, z + zero) - k1_primary_sdf(s, x - zero, y - e, z - zero);
+    float Dz = k1_primary_sdf(s, x + zero, y + zero, z + e) - k1_primary_sdf(s, x - zero, y - zero, z - e);
+    float twoE = (float)(2.0 * K2_NORMAL_EPSILON);
+    out[0] = (float)(1.0 / (double)twoE * (double)Dx);
+    out[1] = (float)(1.0 / (double)twoE * (double)Dy);
+    out[2] = (float)(1.0 / (double)twoE * (double)Dz);
+    normalize3(out);
+}
+
+/* the two materials every scene starts with (scenecompiler.py:426-427 and the basic-lighting text) */
+static void default_shader(const float cam[9], const float n[3], int material_id, float out[3])
+{
+    if (material_id == 0) { /* "return fabs(n);" */
+        out[0] = fabsf(n[0]);
+        out[1] = fabsf(n[1]);
+        out[2] = fabsf(n[2]);
+    } else if (material_id == 1) { /* n_g = n.x*rgt_g+n.y*upp_g+n.z*fwd_g; L = dot(n_g,(0,0,-1)) */
+        float g[3];
+        for (int k = 0; k < 3; k++)
+            g[k] = (n[0] * cam[k] + n[1] * cam[3 + k]) + n[2] * cam[6 + k];
+        float L = (g[0] * 0.0f + g[1] * 0.0f) + g[2] * -1.0f;
+        out[0] = out[1] = out[2] = L;
+    } else { /* shader_bank's trailing return */
+        out[0] = out[1] = out[2] = 1.0f;
+    }
+}
+
+/* shade, k1.cl:285-379 */
+static void k1_shade(const oracle_scene *s, const float cam[9], const float v[3], const float n[3], float out[3])
+{
+    int match = -1;
+    float abc_out[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < s->n_objects; i++) {
+        float dx = v[0] - s->pos[i * 3 + 0], dy = v[1] - s->pos[i * 3 + 1], dz = v[2] - s->pos[i * 3 + 2];
+        float A = dot3(dx, dy, dz, s->right[i * 3 + 0], s->right[i * 3 + 1], s->right[i * 3 + 2]);
+        float B = dot3(dx, dy, dz, s->up[i * 3 + 0], s->up[i * 3 + 1], s->up[i * 3 + 2]);
+        float C = dot3(dx, dy, dz, s->fwd[i * 3 + 0], s->fwd[i * 3 + 1], s->fwd[i * 3 + 2]);
+        float d = s->bank(A, B, C, s->shape_id[i]);
+        if ((double)d < 0.005 * 2.0) { /* SDF_EPSILON*TOLERANCE_FACTOR_MATERIAL; the LAST match wins */
+            match = i;
+            abc_out[0] = A;
+            abc_out[1] = B;
+            abc_out[2] = C;
+        }
+    }
+    if (match != -1) {
+        if (s->shader)
+            s->shader(v, abc_out, n, s->material_id[match], out);
+        else
+            default_shader(cam, n, s->material_id[match], out);
+        return;
+    }
+    float vx = v[0] / 5.0f, vy = v[1] / 5.0f, vz = v[2] / 5.0f;
+    const float radius = (float)0.025;
+    if ((double)axes_cylinder_sdf(sqrtf(vy * vy + vz * vz), vx - 0.5f, 0.5f, radius) < 0.005 * 2.0) {
+        out[0] = 1.0f, out[1] = 0.0f, out[2] = 0.0f;
+        return;
+    }
+    if ((double)axes_cylinder_sdf(sqrtf(vx * vx + vz * vz), vy - 0.5f, 0.5f, radius) < 0.005 * 2.0) {
+        out[0] = 0.0f, out[1] = 1.0f, out[2] = 0.0f;
+        return;
+    }
+    if ((double)axes_cylinder_sdf(sqrtf(vx * vx + vy * vy), vz - 0.5f, 0.5f, radius) < 0.005 * 2.0) {
+        out[0] = 0.0f, out[1] = 0.0f, out[2] = 1.0f;
+        return;
+    }
+    out[0] = (float)(239.0 / 255.0); /* k1.cl:377; "245/255" is an integer division: 0 */
+    out[1] = (float)(66.0 / 255.0);
+    out[2] = (float)(245 / 255);
+}
+
+/* RCOMP/GCOMP/BCOMP + clip, k1.cl:8-10,472-478: (int)(255.0*c) in double, then clamped to a byte.  The
+ * double -> int conversion saturates and maps NaN to 0 (what the GPU's conversion does; C leaves it undefined). */
+static unsigned char colour_byte(float c)
+{
+    double x = 255.0 * (double)c;
+    int v;
+    if (!(x == x))
+        v = 0;
+    else if (x <= -2147483648.0)
+        v = (int)(-2147483647 - 1);
+    else if (x >= 2147483647.0)
+        v = 2147483647;
+    else
+        v = (int)x;
+    return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+void oracle_render_preview(const oracle_scene *s, const float campos[3], const float right[3], const float up[3],
+                           const float forward[3], unsigned char *rgb_out, int threads)
+{
+    threads = pick_threads(threads);
+    float cam[9];
+    for (int k = 0; k < 3; k++)
+        cam[k] = right[k], cam[3 + k] = up[k], cam[6 + k] = forward[k];
+    if (s->set_camera)
+        s->set_camera(right, up, forward); /* rgt_g, upp_g, fwd_g: k1.cl:521-523 */
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 64)
+    for (int tid = 0; tid < 640 * 480; tid++) {
+        int ix = tid % 640, iy = tid / 640;
+        /* k1.cl:515: uv = ((float)(ix-320), -(float)(iy-240)) / (320, 320) */
+        float uvx = (float)(ix - 640 / 2) / 320.0f, uvy = -(float)(iy - 480 / 2) / 320.0f;
+        float r[3] = {uvx, uvy, 1.0f}; /* IFOV */
+        float colour[3] = {1.0f, 1.0f, 1.0f};
+        /* march, k1.cl:419-470 */
+        float ox = dot3(campos[0], campos[1], campos[2], right[0], right[1], right[2]);
+        float oy = dot3(campos[0], campos[1], campos[2], up[0], up[1], up[2]);
+        float oz = dot3(campos[0], campos[1], campos[2], forward[0], forward[1], forward[2]);
+        float rx = dot3(r[0], r[1], r[2], right[0], right[1], right[2]);
+        float ry = dot3(r[0], r[1], r[2], up[0], up[1], up[2]);
+        float rz = dot3(r[0], r[1], r[2], forward[0], forward[1], forward[2]);
+        float d = 0.0f, vx = ox, vy = oy, vz = oz, hit = -1.0f;
+        for (int i = 0; i < 512; i++) { /* MAX_STEPS */
+            float st = (float)((double)k1_primary_sdf(s, vx, vy, vz) * 0.85); /* TOLERANCE_FACTOR_MARCHSTEP */
+            if ((double)st < 0.005) { /* SDF_EPSILON */
+                hit = d;
+                break;
+            }
+            vx = vx + st * rx;
+            vy = vy + st * ry;
+            vz = vz + st * rz;
+            d = d + st;
+            if ((double)d > 64.0) /* MAX_DISTANCE */
+                break;
+        }
+        if ((double)hit > 0.0) { /* k1.cl:548 */
+            float p[3] = {ox + hit * rx, oy + hit * ry, oz + hit * rz};
+            float n[3];
+            k1_get_normal(s, p[0], p[1], p[2], n);
+            k1_shade(s, cam, p, n, colour);
+        }
+        rgb_out[tid * 3 + 0] = colour_byte(colour[0]);
+        rgb_out[tid * 3 + 1] = colour_byte(colour[1]);
+        rgb_out[tid * 3 + 2] = colour_byte(colour[2]);
+    }
+}
 
 /* ------------------------------------------------------------------ */
 /* writeTrianglesToSTL, utils.hpp:41-103: 80 zero bytes, u32 count, per

@@ -30,6 +30,10 @@ typedef struct oracle_scene {
     int n_steps;              /* buildprocedure.txt rows (DrawPane.cpp:355-371) */
     int *steps;               /* [4*n_steps] opcode,left,right,dest           */
     oracle_bank_fn bank;
+    unsigned char *material_id; /* [n_objects] second column of scene.txt (preview only) */
+    /* preview (k1.cl) hooks into a compiled scene.cl; NULL = the two materials every scene starts with */
+    void (*shader)(const float gv[3], const float lv[3], const float n[3], int material_id, float out[3]);
+    void (*set_camera)(const float right[3], const float up[3], const float forward[3]);
 } oracle_scene;
 
 typedef struct oracle_box {   /* box_t{center,diameters} CVector.h:74-78 */
@@ -91,6 +95,15 @@ void oracle_gradient_descent(const oracle_scene *s, int steps, float *tris, size
 void oracle_free(void *p);
 
 /* ---- utils.hpp writers ---------------------------------------------- */
+/* kernel k1 (k1.cl:479-578): the 640x480 RGB preview image, rows top to bottom, 3 bytes per pixel.
+ * PARITY UNPINNED: the reference holds no image fixture and its OpenCL kernel cannot run in the build
+ * container; this is a restatement of the kernel text only.                                            */
+void oracle_render_preview(const oracle_scene *s, const float campos[3], const float right[3], const float up[3],
+                           const float forward[3], unsigned char *rgb_out, int threads);
+void oracle_scene_set_shader(oracle_scene *s,
+                             void (*shader)(const float *, const float *, const float *, int, float *),
+                             void (*set_camera)(const float *, const float *, const float *));
+
 int oracle_write_stl(const char *path, const float *tris, size_t n_tris);
 int oracle_write_ply(const char *path, const float *tris, size_t n_tris);
 

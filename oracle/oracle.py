@@ -104,6 +104,8 @@ def lib():
                                          C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(MeshStats), C.c_int]
         L.oracle_gradient_descent.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
         L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_render_preview.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_scene_set_shader.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_write_stl.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
         L.oracle_write_ply.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
         _lib = L
@@ -141,6 +143,8 @@ class Scene:
             self._ad = ad
             self._bank_lib.dcsg_cpu_set_arbitrary_data.argtypes = [C.c_void_p]
             self._bank_lib.dcsg_cpu_set_arbitrary_data(_ptr(ad))
+            L.oracle_scene_set_shader(self._h, C.cast(self._bank_lib.dcsg_cpu_shader_bank, C.c_void_p),
+                                      C.cast(self._bank_lib.dcsg_cpu_set_camera, C.c_void_p))
 
     @classmethod
     def from_dir(cls, d, use_scene_cl=True):
@@ -184,6 +188,13 @@ class Scene:
         lib().oracle_eval_lattice(self._h, C.byref(bb), res, z0, z1,
                                   _ptr(s) if sdf else None, _ptr(n) if normals else None, threads)
         return s, n
+
+    def render_preview(self, campos, right, up, forward, threads=0):
+        """kernel k1 restated: (480, 640, 3) uint8 image."""
+        v = [np.ascontiguousarray(a, dtype=np.float32) for a in (campos, right, up, forward)]
+        out = np.zeros((480, 640, 3), dtype=np.uint8)
+        lib().oracle_render_preview(self._h, _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(v[3]), _ptr(out), threads)
+        return out
 
     def estimate_bounding_box(self, bb_half_diameter, threads=0):
         bb = Box()

@@ -95,6 +95,36 @@ def test_point_eval_bit_exact(ev, oracle, name, interpreter, monkeypatch):
             assert np.array_equal(np.where(both_nan, 0, bits(got)), np.where(both_nan, 0, bits(want)))
 
 
+def _camera(yaw, pitch, dist):
+    """Orthonormal right / up / forward (float32) and a camera position `dist` behind the origin along forward."""
+    cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+    right = np.array([cy, 0.0, -sy], dtype=np.float32)
+    up = np.array([sy * sp, cp, cy * sp], dtype=np.float32)
+    forward = np.array([sy * cp, -sp, cy * cp], dtype=np.float32)
+    return np.array([0.0, 0.0, -dist], dtype=np.float32), right, up, forward
+
+
+@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups", "ad_table", "const_table", "smooth_blobs"])
+def test_preview_image_equals_oracle(ev, oracle, name):
+    """Kernel k1 (sphere-traced 640x480 preview) against the oracle's restatement, byte for byte:
+    default camera of the reference (DrawPane.h:67 with the identity basis) and a rotated, closer one."""
+    load(ev, name)
+    osc = oracle.Scene.from_dir(scene_dir(name))
+    for cam in (_camera(0.0, 0.0, 15.0), _camera(0.6, -0.35, 9.0)):
+        got = ev.render_preview(*cam)
+        want = osc.render_preview(*cam)
+        assert got.shape == want.shape == (480, 640, 3)
+        diff = np.argwhere((got != want).any(axis=2))
+        assert len(diff) == 0, "first differing pixels (row, col): %s" % diff[:5].tolist()
+        assert len(np.unique(got.reshape(-1, 3), axis=0)) > 16     # an image, not a flat colour
+    # the scene loaded without scene.cl text: standard brushes and materials
+    if name == "sphere":
+        s = read_scene(name)
+        assert ev.build(s["scene.txt"], s["buildprocedure.txt"], None)[0] == 0
+        cam = _camera(0.0, 0.0, 15.0)
+        assert np.array_equal(ev.render_preview(*cam), osc.render_preview(*cam))
+
+
 def test_builtin_bank_equals_jit_bank(ev, oracle):
     """scene.cl = None selects the HIP-native brushes; the generated scene.cl text must agree with them."""
     s = read_scene("flat256")

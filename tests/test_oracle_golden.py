@@ -123,3 +123,25 @@ def test_big_config_goldens_match_survey():
     assert g["design2_7_9_10"]["triangles"] == 1599420
     assert g["design2_7_9_10"]["per_level"] == {"7": 798, "8": 6133, "9": 1592489}
     assert np.allclose(g["design2_7_9_10"]["gd50_sums"], (-77981.315318, -3517190.860812, 78373.765844), atol=2e-4)
+
+
+def test_preview_restatement_sanity(oracle):
+    """kernel k1's restatement (PARITY UNPINNED: the reference holds no image fixture).  What the kernel text
+    implies without running it: background white (k1.cl:531), the three axis markers in pure red / green / blue
+    (k1.cl:341-373), the sphere lit head-on white at the centre (basic lighting, L = dot(n_g, (0,0,-1)) = 1), and
+    a mirror-symmetric silhouette for the symmetric scene."""
+    sc = oracle.Scene.from_dir(scene_dir("sphere"))
+    img = sc.render_preview([0, 0, -15], [1, 0, 0], [0, 1, 0], [0, 0, 1])
+    assert img.shape == (480, 640, 3) and img.dtype == np.uint8
+    assert tuple(img[0, 0]) == (255, 255, 255) and tuple(img[240, 320]) == (255, 255, 255)
+    cols = {tuple(c) for c in np.unique(img.reshape(-1, 3), axis=0).tolist()}
+    assert (255, 0, 0) in cols and (0, 255, 0) in cols       # x and y markers stick out of the sphere (length 5 > 2.5)
+    hit = (img != 255).any(axis=2)
+    # left-right mirror about the optical axis column 320: rows above the x marker are symmetric
+    assert np.array_equal(hit[100:200, 1:320], hit[100:200, 640:320:-1])
+    # the silhouette radius: sphere of radius 2.5 at distance 15 -> tan = 2.5/sqrt(15^2-2.5^2) -> 0.169*320 = 54 px,
+    # so the chord 40 rows above the centre is 2*sqrt(54^2 - 40^2) = 73 px
+    cols_hit = np.flatnonzero(hit[200])
+    assert 68 < cols_hit.max() - cols_hit.min() < 78
+    again = sc.render_preview([0, 0, -15], [1, 0, 0], [0, 1, 0], [0, 0, 1], threads=1)
+    assert np.array_equal(img, again)
