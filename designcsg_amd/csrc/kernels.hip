@@ -1054,6 +1054,45 @@ DCSG_EVAL_KERNEL(dcsg_eval_points_sp, -1)
 // result: int[0..2] min index, int[3..5] max index (both seeded by the host with the
 // "no interior point" sentinels), unsigned long long at byte 32: interior count.
 // ---------------------------------------------------------------------------
+// Stage A's reduction: wave min / max / sum, one combine per block through LDS, then at most seven atomics per
+// block -- and none from blocks that saw no interior point (most of the probe cube).  Same-address atomics
+// serialise in L2: issued per wave they cost more than the 16.7 M evaluations (1.34 ms -> see DESIGN.md).
+__device__ __forceinline__ void dcsg_bbox_commit(int (&mn)[3], int (&mx)[3], unsigned int cnt, int* __restrict__ result)
+{
+    __shared__ int part[DCSG_BLOCK / DCSG_WAVE][8];
+    for (int k = 0; k < 3; k++) {
+        mn[k] = wave_min(mn[k]);
+        mx[k] = wave_max(mx[k]);
+    }
+    cnt = wave_sum(cnt);
+    const int wave = threadIdx.x / DCSG_WAVE;
+    if ((threadIdx.x & (DCSG_WAVE - 1)) == 0) {
+        for (int k = 0; k < 3; k++) {
+            part[wave][k] = mn[k];
+            part[wave][3 + k] = mx[k];
+        }
+        part[wave][6] = (int)cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int total = 0;
+        for (int w = 0; w < DCSG_BLOCK / DCSG_WAVE; w++) {
+            for (int k = 0; k < 3; k++) {
+                mn[k] = part[w][k] < mn[k] ? part[w][k] : mn[k];
+                mx[k] = part[w][3 + k] > mx[k] ? part[w][3 + k] : mx[k];
+            }
+            total += (unsigned int)part[w][6];
+        }
+        if (total) {
+            for (int k = 0; k < 3; k++) {
+                atomicMin(&result[k], mn[k]);
+                atomicMax(&result[3 + k], mx[k]);
+            }
+            atomicAdd(reinterpret_cast<unsigned long long*>(result + 8), (unsigned long long)total);
+        }
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void dcsg_bbox_body(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg,
                                                double bb_eps, int* __restrict__ result)
@@ -1086,18 +1125,7 @@ __device__ __forceinline__ void dcsg_bbox_body(const uint4* __restrict__ blob, i
             mx[2] = iz > mx[2] ? iz : mx[2];
         }
     }
-    for (int k = 0; k < 3; k++) {
-        mn[k] = wave_min(mn[k]);
-        mx[k] = wave_max(mx[k]);
-    }
-    cnt = wave_sum(cnt);
-    if ((threadIdx.x & (DCSG_WAVE - 1)) == 0) {
-        for (int k = 0; k < 3; k++) {
-            atomicMin(&result[k], mn[k]);
-            atomicMax(&result[3 + k], mx[k]);
-        }
-        atomicAdd(reinterpret_cast<unsigned long long*>(result + 8), (unsigned long long)cnt);
-    }
+    dcsg_bbox_commit(mn, mx, cnt, result);
 }
 
 #define DCSG_BBOX_KERNEL(NAME, K)                                                                                   \
@@ -1603,9 +1631,10 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
     int mx[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
     unsigned int cnt = 0;
     for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < total; i += gridDim.x * DCSG_BLOCK) {
-        int iz = (int)(i & 255u) - 128;
-        int iy = (int)((i >> 8) & 255u) - 128;
-        int ix = (int)(i >> 16) - 128;
+        // a wave's 64 consecutive probes form a 4 x 4 x 4 brick (the result does not depend on the visiting order)
+        int iz = (int)((((i >> 6) & 63u) << 2) | (i & 3u)) - 128;
+        int iy = (int)((((i >> 12) & 63u) << 2) | ((i >> 2) & 3u)) - 128;
+        int ix = (int)(((i >> 18) << 2) | ((i >> 4) & 3u)) - 128;
         float x = half_neg + cd * (float)ix;
         float y = half_neg + cd * (float)iy;
         float z = half_neg + cd * (float)iz;
@@ -1622,18 +1651,7 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
             mx[2] = iz > mx[2] ? iz : mx[2];
         }
     }
-    for (int k = 0; k < 3; k++) {
-        mn[k] = wave_min(mn[k]);
-        mx[k] = wave_max(mx[k]);
-    }
-    cnt = wave_sum(cnt);
-    if ((threadIdx.x & (DCSG_WAVE - 1)) == 0) {
-        for (int k = 0; k < 3; k++) {
-            atomicMin(&result[k], mn[k]);
-            atomicMax(&result[3 + k], mx[k]);
-        }
-        atomicAdd(reinterpret_cast<unsigned long long*>(result + 8), (unsigned long long)cnt);
-    }
+    dcsg_bbox_commit(mn, mx, cnt, result);
 }
 
 // Projection: consecutive vertices of the triangle buffer come from the same or neighbouring octree leaves,
