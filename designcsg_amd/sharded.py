@@ -62,26 +62,37 @@ class HipBackend:
         return out
 
 
-def exchange_halo(sdf, normals, plane_floats, n_own, rank, world, group=None):
+def exchange_halo(sdf, normals, plane_floats, n_own, rank, world, group=None, host_staged=False):
     """Plane 0 of every rank > 0 goes to the halo plane (index n_own) of rank-1.  Point-to-point between Z
-    neighbours: on xGMI each pair has a direct link, so nothing is routed through a ring."""
-    reqs = []
+    neighbours: on xGMI each pair has a direct link, so nothing is routed through a ring.
+    host_staged: the planes travel through host memory (gloo rehearsals of the N>1 logic, e.g. several ranks on
+    one GPU); the product path (RCCL) sends the device tensors directly."""
+    reqs, landing = [], []
+    out = lambda t: t.cpu() if host_staged else t
     if rank > 0:
-        reqs.append(dist.isend(sdf[:plane_floats], rank - 1, group=group))
+        reqs.append(dist.isend(out(sdf[:plane_floats]), rank - 1, group=group))
         if normals is not None:
-            reqs.append(dist.isend(normals[:3 * plane_floats], rank - 1, group=group))
+            reqs.append(dist.isend(out(normals[:3 * plane_floats]), rank - 1, group=group))
     if rank < world - 1:
-        reqs.append(dist.irecv(sdf[n_own * plane_floats:(n_own + 1) * plane_floats], rank + 1, group=group))
+        dst = [sdf[n_own * plane_floats:(n_own + 1) * plane_floats]]
         if normals is not None:
-            reqs.append(dist.irecv(normals[3 * n_own * plane_floats:3 * (n_own + 1) * plane_floats], rank + 1,
-                                   group=group))
+            dst.append(normals[3 * n_own * plane_floats:3 * (n_own + 1) * plane_floats])
+        for d in dst:
+            buf = torch.empty(d.shape, dtype=d.dtype) if host_staged else d
+            landing.append((d, buf))
+            reqs.append(dist.irecv(buf, rank + 1, group=group))
     for r in reqs:
         r.wait()
+    if host_staged:
+        for d, buf in landing:
+            d.copy_(buf)
 
 
-def gather_triangles(tris, rank, world, group=None):
+def gather_triangles(tris, rank, world, group=None, host_staged=False):
     """Variable-length gather to rank 0: counts by all_gather, payload padded to the largest count.
     Returns (concatenated (T,3,3) tensor on rank 0 else None, list of per-rank counts)."""
+    if host_staged:
+        tris = tris.cpu()
     count = torch.tensor([tris.shape[0]], dtype=torch.int64, device=tris.device)
     counts = [torch.zeros_like(count) for _ in range(world)]
     dist.all_gather(counts, count, group=group)
@@ -96,7 +107,7 @@ def gather_triangles(tris, rank, world, group=None):
     return torch.cat([b[:c] for b, c in zip(bufs, counts)]), counts
 
 
-def sharded_export(backend, cfg, rank, world, dense_normals=False, group=None, check_halo=False):
+def sharded_export(backend, cfg, rank, world, dense_normals=False, group=None, check_halo=False, host_staged=False):
     """Runs the export stages on this rank's slab.  cfg: ExportConfig (parse_export_config).
     Returns dict(triangles=(T,3,3) CPU numpy array on rank 0 / None elsewhere, counts, box, stats)."""
     center, diameter, interior = backend.estimate_bounding_box(cfg.bounding_box_half_diameter)
@@ -112,7 +123,7 @@ def sharded_export(backend, cfg, rank, world, dense_normals=False, group=None, c
     # own planes (the halo plane hi is the neighbour's, except on the last rank)
     backend.sweep(center, diameter, res, lo, lo + n_own, sdf, nrm)
     if world > 1:
-        exchange_halo(sdf, nrm, plane, hi - lo, rank, world, group)
+        exchange_halo(sdf, nrm, plane, hi - lo, rank, world, group, host_staged)
         if check_halo and not last:
             # self-check: the received plane must equal what this rank computes for it
             chk = backend.alloc(plane)
@@ -123,7 +134,7 @@ def sharded_export(backend, cfg, rank, world, dense_normals=False, group=None, c
     tris = backend.project_and_fetch(cfg.gradient_descent_steps)
     assert tris.shape[0] == n_tris
     if world > 1:
-        all_tris, counts = gather_triangles(tris, rank, world, group)
+        all_tris, counts = gather_triangles(tris, rank, world, group, host_staged)
     else:
         all_tris, counts = tris, [int(tris.shape[0])]
     return dict(triangles=None if all_tris is None else all_tris.cpu().numpy(), counts=counts,

@@ -26,6 +26,12 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--dense-normals", action="store_true")
     ap.add_argument("--check-halo", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal on a box with fewer GPUs than ranks: ranks share GPUs, planes and triangles "
+                         "are staged through host memory")
+    ap.add_argument("--verify-single", action="store_true",
+                    help="rank 0 also exports the whole lattice on its own and checks that the stitched mesh is the "
+                         "same triangle set")
     args = ap.parse_args()
 
     import torch
@@ -36,9 +42,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     lines = open(os.path.join(args.scene_dir, "exportConfig.txt")).read().split("\n")
     if args.levels:
         lines[1:4] = [str(v) for v in args.levels]
@@ -55,16 +67,27 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     res = sharded_export(HipBackend(ev, "cuda:%d" % local_rank), cfg, rank, world, dense_normals=args.dense_normals,
-                         check_halo=args.check_halo)
+                         check_halo=args.check_halo, host_staged=args.backend == "gloo")
     t_compute = time.perf_counter() - t0
     if rank == 0:
         tris = res["triangles"]
         if args.out:
             write_stl(args.out + ".stl", tris)
             write_ply(args.out + ".ply", tris)
-        print(json.dumps({"n_gpus": world, "triangles": int(len(tris)), "per_rank_triangles": res["counts"],
-                          "box": res["box"][:2], "export_s": round(time.perf_counter() - t0, 4),
-                          "compute_and_gather_s": round(t_compute, 4)}))
+        out = {"n_gpus": world, "backend": args.backend, "triangles": int(len(tris)), "per_rank_triangles": res["counts"],
+               "box": res["box"][:2], "export_s": round(time.perf_counter() - t0, 4),
+               "compute_and_gather_s": round(t_compute, 4)}
+        if args.verify_single:
+            import numpy as np
+            whole = sharded_export(HipBackend(ev, "cuda:%d" % local_rank), cfg, 0, 1, dense_normals=args.dense_normals)
+            key = lambda t: np.sort(np.ascontiguousarray(t, dtype=np.float32).reshape(-1, 9).view(np.uint32).copy().view(
+                [("", np.uint32)] * 9), axis=0)
+            same = len(whole["triangles"]) == len(tris) and bool(np.array_equal(key(whole["triangles"]), key(tris)))
+            out["equals_single_gpu_export_as_a_set"] = same
+            if not same:
+                print(json.dumps(out))
+                sys.exit("stitched mesh differs from the single-GPU mesh")
+        print(json.dumps(out))
     ev.close()
     if world > 1:
         dist.destroy_process_group()
