@@ -17,6 +17,7 @@ EXPORT_DENSE_NORMALS = 1
 EXPORT_SPARSE_NORMALS = 2
 EXPORT_INDEXED_PLY = 4     # opt-in writers beyond the reference's, include/dcsg.h
 EXPORT_STL_NORMALS = 8
+EXPORT_DENSE_SWEEP = 16
 
 
 class ExportConfig(C.Structure):
@@ -41,7 +42,8 @@ class ExportStats(C.Structure):
                 ("mesh", MeshStats),
                 ("t_bbox", C.c_double), ("t_sweep", C.c_double), ("t_mesh", C.c_double),
                 ("t_project", C.c_double), ("t_download", C.c_double), ("t_write_stl", C.c_double),
-                ("t_write_ply", C.c_double), ("t_total", C.c_double), ("sweep_kernel_ms", C.c_double)]
+                ("t_write_ply", C.c_double), ("t_total", C.c_double), ("sweep_kernel_ms", C.c_double),
+                ("swept_points", C.c_uint64), ("swept_nodes", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every prototype of include/dcsg.h

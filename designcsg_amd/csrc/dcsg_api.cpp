@@ -39,6 +39,7 @@ struct Kernels {
     hipFunction_t sweep[5] = {}, eval_points[5] = {}, bbox[5] = {}, project[5] = {};
     hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr;
     hipFunction_t sweep_sp2 = nullptr;  // specialised sweep, two planes per thread (scene modules only)
+    hipFunction_t sweep_nodes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // node-wise sweep per variant
     hipFunction_t dd_insert = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
 };
 
@@ -57,6 +58,7 @@ struct dcsg_ctx {
     size_t max_lds = 65536;
     hipStream_t stream = nullptr;
     hipModule_t builtin_mod = nullptr, scene_mod = nullptr;
+    DevBuf d_node_mask;                 // node-wise sweep: which nodes of the sweep level hold lattice values
     hipModule_t preview_mod = nullptr;  // scene.cl as given + kernels, built on the first dcsg_render_preview of a scene
     hipFunction_t preview_fn = nullptr;
     std::string scene_cl_text;
@@ -134,7 +136,7 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
             const char* name;
             hipFunction_t* f;
         } tab[] = {{"dcsg_sweep", &k.sweep[v]}, {"dcsg_eval_points", &k.eval_points[v]}, {"dcsg_bbox", &k.bbox[v]},
-                   {"dcsg_project", &k.project[v]}};
+                   {"dcsg_project", &k.project[v]}, {"dcsg_sweep_nodes", &k.sweep_nodes[v]}};
         for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, (std::string(t.name) + suffix[v]).c_str()));
     }
     struct {
@@ -147,6 +149,7 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
     for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
     if (!scene_module) {
         HIPCHK(c, hipModuleGetFunction(&k.sweep[4], mod, "dcsg_sweep_c4"));
+        HIPCHK(c, hipModuleGetFunction(&k.sweep_nodes[4], mod, "dcsg_sweep_nodes_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.bbox[4], mod, "dcsg_bbox_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.project[4], mod, "dcsg_project_c4"));
         k.eval_points[4] = k.eval_points[1];  // arbitrary points have no spatial coherence to exploit
@@ -394,7 +397,7 @@ void dcsg_destroy(dcsg_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_blob,  &c->d_ad,         &c->d_tri_table, &c->d_pts,  &c->d_out,     &c->d_nodes[0],
                       &c->d_nodes[1], &c->d_info,    &c->d_block_sums, &c->d_small, &c->d_tris, &c->d_lat_sdf,
-                      &c->d_lat_nrm, &c->d_dd_table, &c->d_dd_rep, &c->d_dd_slot, &c->d_dd_compact};
+                      &c->d_lat_nrm, &c->d_dd_table, &c->d_dd_rep, &c->d_dd_slot, &c->d_dd_compact, &c->d_node_mask};
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->scene_mod) hipModuleUnload(c->scene_mod);
@@ -672,10 +675,23 @@ int dcsg_parse_export_config(const char* txt, dcsg_export_config* out)
     return 0;
 }
 
-// Mesh::getSurface, mesh.hpp:82-389, level-synchronous on the device.
-int dcsg_mesh_lattice_device(dcsg_ctx* c, const float center[3], float diameter, const dcsg_export_config* cfg,
-                             const float* d_sdf, const float* d_normals, int z_lo, int z_hi, int z_own_lo,
-                             int z_own_hi, uint64_t* n_triangles, dcsg_mesh_stats* stats, void* stream_v)
+}  // extern "C"
+
+namespace {
+// Node-wise sweep request of dcsg_export: at level `level` (the first level whose nodes the cull rule can drop for
+// good: max(minimumOctreeLevel, 2)) the lattice values inside the nodes that reached the mesher are evaluated into
+// d_sdf / d_nrm and the mesher reads them from there on; the levels above sample on demand.
+struct NodeSweep {
+    int level = 0;
+    float* d_sdf = nullptr;
+    float* d_nrm = nullptr;  // NULL: normals on demand
+    double ms = 0;           // device time of the sweep kernel
+    uint64_t nodes = 0, points = 0;
+};
+
+int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_export_config* cfg, const float* d_sdf,
+              const float* d_normals, int z_lo, int z_hi, int z_own_lo, int z_own_hi, uint64_t* n_triangles,
+              dcsg_mesh_stats* stats, void* stream_v, NodeSweep* ns)
 {
     int r = need_scene(c);
     if (r) return r;
@@ -748,6 +764,36 @@ int dcsg_mesh_lattice_device(dcsg_ctx* c, const float center[3], float diameter,
     for (int level = 2; level <= cfg->max_level && n_nodes > 0; level++) {
         P.level = level;
         for (int k = 0; k < 3; k++) P.hd[k] = hd[k];
+        if (ns && level == ns->level) {
+            // the node list of this level is complete: evaluate the lattice inside these nodes, then read from it
+            const int shift = cfg->grid_level - level;
+            const size_t N = (size_t)1 << level;
+            if ((r = ensure(c, c->d_node_mask, N * N * N))) return r;
+            HIPCHK(c, hipMemsetAsync(c->d_node_mask.p, 0, N * N * N, s));
+            const float* d_list = (const float*)c->d_nodes[cur].p;
+            unsigned char* d_mask = (unsigned char*)c->d_node_mask.p;
+            int lvl = level, sh = shift;
+            void* args[] = {(void*)&blob, &nv, &P.lat, (void*)&d_list, &n_nodes, &sh, &lvl, (void*)&ns->d_sdf, (void*)&ns->d_nrm,
+                            (void*)&d_mask};
+            HIPCHK(c, hipEventRecord(c->ev0, s));
+            if ((r = launch(c, c->k->sweep_nodes[c->variant], n_nodes, DCSG_BLOCK, c->scene.lds_bytes(), s, args))) return r;
+            HIPCHK(c, hipEventRecord(c->ev1, s));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            ns->ms = ms;
+            ns->nodes = n_nodes;
+            const uint64_t side = ((uint64_t)1 << shift) + 1;
+            ns->points = (uint64_t)n_nodes * side * side * side;
+            d_sdf = ns->d_sdf;
+            d_normals = ns->d_nrm;
+            P.z_lo = 0;
+            P.z_hi = res;
+            P.has_normals = d_normals ? 1 : 0;
+            P.node_mask = d_mask;
+            P.mask_level = level;
+            P.mask_shift = shift;
+        }
         unsigned n_blocks = (n_nodes + DCSG_BLOCK - 1) / DCSG_BLOCK;
         if ((r = ensure(c, c->d_info, (size_t)n_nodes * sizeof(unsigned short)))) return r;
         if ((r = ensure(c, c->d_block_sums, (size_t)n_blocks * 2 * sizeof(unsigned)))) return r;
@@ -800,6 +846,18 @@ int dcsg_mesh_lattice_device(dcsg_ctx* c, const float center[3], float diameter,
     if (n_triangles) *n_triangles = n_tris;
     if (stats) *stats = st;
     return 0;
+}
+}  // namespace
+
+extern "C" {
+
+// Mesh::getSurface, mesh.hpp:82-389, level-synchronous on the device.
+int dcsg_mesh_lattice_device(dcsg_ctx* c, const float center[3], float diameter, const dcsg_export_config* cfg,
+                             const float* d_sdf, const float* d_normals, int z_lo, int z_hi, int z_own_lo,
+                             int z_own_hi, uint64_t* n_triangles, dcsg_mesh_stats* stats, void* stream_v)
+{
+    return mesh_impl(c, center, diameter, cfg, d_sdf, d_normals, z_lo, z_hi, z_own_lo, z_own_hi, n_triangles, stats, stream_v,
+                     nullptr);
 }
 
 int dcsg_project_vertices_device(dcsg_ctx* c, float* d_xyz, size_t n_vertices, int steps, void* stream)
@@ -1235,31 +1293,54 @@ int dcsg_export(dcsg_ctx* c, const char* cfg_txt, const char* stl_path, const ch
     if ((r = ensure(c, c->d_lat_sdf, n_pts * sizeof(float)))) return r;
     if (dense_normals && (r = ensure(c, c->d_lat_nrm, n_pts * 3 * sizeof(float)))) return r;
     float diam3[3] = {diameter, diameter, diameter};
-    // one launch covers < 2^32 points; sweep in Z ranges when the lattice is larger
-    const int planes_per = (int)(0xf0000000ull / (n1 * n1)) > 0 ? (int)(0xf0000000ull / (n1 * n1)) : 1;
-    double sweep_ms = 0;
-    for (int z0 = 0; z0 < (int)n1; z0 += planes_per) {
-        int z1 = z0 + planes_per < (int)n1 ? z0 + planes_per : (int)n1;
-        float* sd = (float*)c->d_lat_sdf.p + (size_t)z0 * n1 * n1;
-        float* nr = dense_normals ? (float*)c->d_lat_nrm.p + (size_t)z0 * n1 * n1 * 3 : nullptr;
-        if ((r = sweep_device(c, st.box_center, diam3, res, z0, z1, sd, nr, c->stream, true))) return r;
-        double ms = 0;
-        if ((r = dcsg_last_sweep_ms(c, &ms))) return r;
-        sweep_ms += ms;
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    st.sweep_kernel_ms = sweep_ms;
-    st.t_sweep = now_s() - t0;
-
-    // mesher (retopologize = identity: the reference's is undefined behaviour)
-    t0 = now_s();
+    // Node-wise sweep (default): the mesher's first levels sample on demand; at level max(min,2) -- the first whose
+    // nodes the cull rule can drop for good -- the lattice is evaluated inside the nodes that are still alive, which
+    // is everything later levels can read (a sample outside them, should rounding ever produce one, is evaluated on
+    // demand: dcsg_lattice_point_written).  Worth it while a node is a small block; otherwise, or on request, the
+    // whole lattice is swept.
+    const int sweep_level = cfg.min_level > 2 ? cfg.min_level : 2;
+    const bool node_wise = !(flags & DCSG_EXPORT_DENSE_SWEEP) && !getenv("DCSG_DENSE_SWEEP") && sweep_level <= cfg.max_level &&
+                           cfg.grid_level - sweep_level <= 4 && cfg.grid_level - sweep_level >= 0;
     uint64_t n_tris = 0;
-    if ((r = dcsg_mesh_lattice_device(c, st.box_center, diameter, &cfg, (const float*)c->d_lat_sdf.p,
-                                      dense_normals ? (const float*)c->d_lat_nrm.p : nullptr, 0, res, 0, res, &n_tris,
-                                      &st.mesh, c->stream)))
-        return r;
+    if (node_wise) {
+        NodeSweep ns;
+        ns.level = sweep_level;
+        ns.d_sdf = (float*)c->d_lat_sdf.p;
+        ns.d_nrm = dense_normals ? (float*)c->d_lat_nrm.p : nullptr;
+        if ((r = mesh_impl(c, st.box_center, diameter, &cfg, nullptr, nullptr, 0, res, 0, res, &n_tris, &st.mesh, c->stream, &ns)))
+            return r;
+        st.sweep_kernel_ms = ns.ms;
+        st.swept_points = ns.points;
+        st.swept_nodes = ns.nodes;
+        st.t_sweep = ns.ms * 1e-3;
+        st.t_mesh = now_s() - t0 - st.t_sweep;
+    } else {
+        // one launch covers < 2^32 points; sweep in Z ranges when the lattice is larger
+        const int planes_per = (int)(0xf0000000ull / (n1 * n1)) > 0 ? (int)(0xf0000000ull / (n1 * n1)) : 1;
+        double sweep_ms = 0;
+        for (int z0 = 0; z0 < (int)n1; z0 += planes_per) {
+            int z1 = z0 + planes_per < (int)n1 ? z0 + planes_per : (int)n1;
+            float* sd = (float*)c->d_lat_sdf.p + (size_t)z0 * n1 * n1;
+            float* nr = dense_normals ? (float*)c->d_lat_nrm.p + (size_t)z0 * n1 * n1 * 3 : nullptr;
+            if ((r = sweep_device(c, st.box_center, diam3, res, z0, z1, sd, nr, c->stream, true))) return r;
+            double ms = 0;
+            if ((r = dcsg_last_sweep_ms(c, &ms))) return r;
+            sweep_ms += ms;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        st.sweep_kernel_ms = sweep_ms;
+        st.swept_points = n_pts;
+        st.t_sweep = now_s() - t0;
+
+        // mesher (retopologize = identity: the reference's is undefined behaviour)
+        t0 = now_s();
+        if ((r = dcsg_mesh_lattice_device(c, st.box_center, diameter, &cfg, (const float*)c->d_lat_sdf.p,
+                                          dense_normals ? (const float*)c->d_lat_nrm.p : nullptr, 0, res, 0, res, &n_tris,
+                                          &st.mesh, c->stream)))
+            return r;
+        st.t_mesh = now_s() - t0;
+    }
     st.triangles = n_tris;
-    st.t_mesh = now_s() - t0;
 
     t0 = now_s();
     if ((r = dcsg_project_triangles(c, cfg.gradient_descent_steps, c->stream))) return r;

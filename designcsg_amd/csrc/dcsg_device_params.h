@@ -28,6 +28,11 @@ struct DcsgMeshParams {
     int has_normals;   // nrm[] resident; otherwise normals are evaluated on demand
     int z_own_lo, z_own_hi;  // Z-slab owned by this rank: nodes that do not intersect it are dropped,
                              // leaves emit triangles only where their lowest plane is in [z_own_lo, z_own_hi)
+    // Node-wise sweep (dcsg_export): the lattice holds values only inside the octree nodes of level `mask_level`
+    // that reached the mesher; node_mask[(nz*N + ny)*N + nx] != 0 (N = 2^mask_level) marks them, node (nx,ny,nz)
+    // covering lattice indices [n << mask_shift, (n+1) << mask_shift] per axis.  NULL = the lattice is dense.
+    const unsigned char* node_mask;
+    int mask_level, mask_shift;
 };
 
 struct DcsgCamera {  // kernel k1's campos / right / up / forward buffers (k1.cl:481-486)

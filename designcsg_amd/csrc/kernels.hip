@@ -926,6 +926,79 @@ DCSG_SWEEP_KERNEL(dcsg_sweep_s4, 4)
 DCSG_SWEEP_KERNEL(dcsg_sweep_s8, 8)
 #ifdef DCSG_HAVE_SPEC
 DCSG_SWEEP_KERNEL(dcsg_sweep_sp, -1)
+#endif
+
+// ---------------------------------------------------------------------------
+// Node-wise sweep (dcsg_export): the lattice values of the octree nodes of one level -- the nodes that reached the
+// mesher at the first level where the cull rule can drop a node for good -- instead of the whole lattice.  This is
+// the reference's lazy block cache (ISV.hpp:15-60) turned into one launch: a node of level m covers (2^(g-m)+1)^3
+// lattice points; one block per node, points shared with a neighbour are written by both (same bits).  The node's
+// index on the level's grid comes from its snapped centre; node_mask records it for dcsg_lattice_point_written.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void dcsg_node_origin(const DcsgLattice& L, const float* __restrict__ nodes, unsigned int n, int shift,
+                                                 int level, unsigned char* __restrict__ node_mask, int (&i0)[3])
+{
+    const int N = 1 << level;
+    int a[3];
+    for (int k = 0; k < 3; k++) {
+        a[k] = dcsg_snap(L, k, nodes[(size_t)n * 3 + k]) >> shift;
+        a[k] = a[k] > N - 1 ? N - 1 : a[k];
+        i0[k] = a[k] << shift;
+    }
+    if (threadIdx.x == 0) node_mask[((size_t)a[2] * N + (size_t)a[1]) * N + (size_t)a[0]] = 1;
+}
+
+template <int K>
+__device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ blob, int n_vec4, const DcsgLattice& L,
+                                                      const float* __restrict__ nodes, unsigned int n_nodes, int shift, int level,
+                                                      float* __restrict__ sdf_out, float* __restrict__ nrm_out,
+                                                      unsigned char* __restrict__ node_mask)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    const unsigned int n1 = (unsigned int)L.res + 1u, side = (1u << shift) + 1u, pts = side * side * side;
+    for (unsigned int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
+        int i0[3];
+        dcsg_node_origin(L, nodes, n, shift, level, node_mask, i0);
+        for (unsigned int p = threadIdx.x; p < pts; p += DCSG_BLOCK) {
+            unsigned int lz = p / (side * side), r = p - lz * side * side, ly = r / side, lx = r - ly * side;
+            unsigned int ix = (unsigned int)i0[0] + lx, iy = (unsigned int)i0[1] + ly, iz = (unsigned int)i0[2] + lz;
+            float x = dcsg_lattice_coord(L, 0, (int)ix), y = dcsg_lattice_coord(L, 1, (int)iy), z = dcsg_lattice_coord(L, 2, (int)iz);
+            float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+            if (K == 0) {
+                if (sdf_out) sd = dcsg_primary_sdf(s, x, y, z);
+                if (nrm_out) dcsg_get_normal(s, x, y, z, nx, ny, nz);
+#ifdef DCSG_HAVE_SPEC
+            } else if (K < 0) {
+                dcsg_stencil_spec<true>(x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
+#endif
+            } else {
+                dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
+            }
+            size_t idx = ((size_t)iz * n1 + iy) * n1 + ix;
+            if (sdf_out) sdf_out[idx] = sd;
+            if (nrm_out) {
+                float* o = nrm_out + idx * 3;
+                o[0] = nx;
+                o[1] = ny;
+                o[2] = nz;
+            }
+        }
+    }
+}
+
+#define DCSG_SWEEP_NODES_KERNEL(NAME, K)                                                                             \
+    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                         \
+    NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,                 \
+         unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,       \
+         unsigned char* __restrict__ node_mask)                                                                      \
+    {                                                                                                                \
+        dcsg_sweep_nodes_body<K>(blob, n_vec4, L, nodes, n_nodes, shift, level, sdf_out, nrm_out, node_mask);        \
+    }
+DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes, 0)
+DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_s4, 4)
+DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_s8, 8)
+#ifdef DCSG_HAVE_SPEC
+DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_sp, -1)
 
 // Specialised fused sweep, two lattice planes per thread: point (ix,iy,iz) and (ix,iy,iz+1) are evaluated
 // in one call (14 stencil points).  The object transform is A = (dx*rx + dy*ry) + dz*rz (k2.cl:111,
@@ -1174,6 +1247,28 @@ struct Sampler {
     const SceneLds* scene;
 };
 
+// Node-wise sweep: is lattice point (ix,iy,iz) inside a swept node?  A point on a node face belongs to two nodes per
+// axis, so up to eight mask bytes are looked at (one for a point strictly inside a node).
+__device__ __forceinline__ bool dcsg_lattice_point_written(const DcsgMeshParams& P, int ix, int iy, int iz)
+{
+    if (!P.node_mask) return true;
+    const int sh = P.mask_shift, N = 1 << P.mask_level, low = (1 << sh) - 1;
+    int c[3] = {ix, iy, iz}, a[3], n_alt[3];
+    for (int k = 0; k < 3; k++) {
+        a[k] = c[k] >> sh;
+        n_alt[k] = ((c[k] & low) == 0 && a[k] > 0) ? 2 : 1;  // also the node below
+        if (a[k] > N - 1) {                                   // index res: only the last node holds it
+            a[k] = N - 1;
+            n_alt[k] = 1;
+        }
+    }
+    for (int dz = 0; dz < n_alt[2]; dz++)
+        for (int dy = 0; dy < n_alt[1]; dy++)
+            for (int dx = 0; dx < n_alt[0]; dx++)
+                if (P.node_mask[((size_t)(a[2] - dz) * N + (size_t)(a[1] - dy)) * N + (size_t)(a[0] - dx)]) return true;
+    return false;
+}
+
 // The value AT THE SNAPPED LATTICE POINT (ISV3D64::getValue, ISV.hpp:15-60).  Planes that
 // are not resident on this rank are evaluated directly: a sample is a pure function of its
 // lattice index, so both paths give the same bits.
@@ -1181,7 +1276,7 @@ __device__ __forceinline__ float sample_sdf(const Sampler& S, const float p[3])
 {
     const DcsgLattice& L = S.P->lat;
     int ix = dcsg_snap(L, 0, p[0]), iy = dcsg_snap(L, 1, p[1]), iz = dcsg_snap(L, 2, p[2]);
-    if (iz >= S.P->z_lo && iz <= S.P->z_hi) {
+    if (iz >= S.P->z_lo && iz <= S.P->z_hi && dcsg_lattice_point_written(*S.P, ix, iy, iz)) {
         size_t n1 = (size_t)L.res + 1;
         return S.sdf[((size_t)(iz - S.P->z_lo) * n1 + iy) * n1 + ix];
     }
@@ -1193,7 +1288,7 @@ __device__ __forceinline__ void sample_normal(const Sampler& S, const float p[3]
 {
     const DcsgLattice& L = S.P->lat;
     int ix = dcsg_snap(L, 0, p[0]), iy = dcsg_snap(L, 1, p[1]), iz = dcsg_snap(L, 2, p[2]);
-    if (S.P->has_normals && iz >= S.P->z_lo && iz <= S.P->z_hi) {
+    if (S.P->has_normals && iz >= S.P->z_lo && iz <= S.P->z_hi && dcsg_lattice_point_written(*S.P, ix, iy, iz)) {
         size_t n1 = (size_t)L.res + 1;
         const float* q = S.nrm + (((size_t)(iz - S.P->z_lo) * n1 + iy) * n1 + ix) * 3;
         n[0] = q[0];
@@ -1652,6 +1747,51 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
         }
     }
     dcsg_bbox_commit(mn, mx, cnt, result);
+}
+
+// Node-wise sweep with tile culling: the node's box is the tile.
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,
+                    unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,
+                    unsigned char* __restrict__ node_mask)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    const unsigned int n1 = (unsigned int)L.res + 1u, side = (1u << shift) + 1u, pts = side * side * side;
+    const float pad = nrm_out ? (float)K2_NORMAL_EPSILON * 1.01f : 0.0f;
+    for (unsigned int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
+        int i0[3];
+        dcsg_node_origin(L, nodes, n, shift, level, node_mask, i0);
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; k++) {
+            lo[k] = dcsg_lattice_coord(L, k, i0[k]);
+            hi[k] = dcsg_lattice_coord(L, k, i0[k] + (int)side - 1);
+        }
+        float hx = 0.5f * __builtin_fabsf(hi[0] - lo[0]) + pad, hy = 0.5f * __builtin_fabsf(hi[1] - lo[1]) + pad,
+              hz = 0.5f * __builtin_fabsf(hi[2] - lo[2]) + pad;
+        float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
+        const unsigned short* list;
+        int n_list = dcsg_build_block_list(s, n_vec4, 0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2]), R, list);
+        for (unsigned int p0 = 0; p0 < pts; p0 += DCSG_BLOCK) {
+            unsigned int p = p0 + threadIdx.x;
+            bool valid = p < pts;
+            unsigned int cp = valid ? p : pts - 1u;  // idle lanes evaluate the last point and store nothing
+            unsigned int lz = cp / (side * side), r = cp - lz * side * side, ly = r / side, lx = r - ly * side;
+            unsigned int ix = (unsigned int)i0[0] + lx, iy = (unsigned int)i0[1] + ly, iz = (unsigned int)i0[2] + lz;
+            float x = dcsg_lattice_coord(L, 0, (int)ix), y = dcsg_lattice_coord(L, 1, (int)iy), z = dcsg_lattice_coord(L, 2, (int)iz);
+            float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+            dcsg_stencil<4>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz, list, n_list);
+            if (valid) {
+                size_t idx = ((size_t)iz * n1 + iy) * n1 + ix;
+                if (sdf_out) sdf_out[idx] = sd;
+                if (nrm_out) {
+                    float* o = nrm_out + idx * 3;
+                    o[0] = nx;
+                    o[1] = ny;
+                    o[2] = nz;
+                }
+            }
+        }
+    }
 }
 
 // Projection: consecutive vertices of the triangle buffer come from the same or neighbouring octree leaves,

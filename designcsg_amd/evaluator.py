@@ -189,12 +189,12 @@ class Evaluator:
         return out
 
     def export(self, export_config_txt, stl_path=None, ply_path=None, dense_normals=False, indexed_ply=False,
-               stl_normals=False):
+               stl_normals=False, dense_sweep=False):
         """MyFrame::OnExportInner end to end on this GPU.  indexed_ply / stl_normals select the opt-in writers
         (shared vertices; real facet normals) instead of the reference's file layouts."""
         st = ExportStats()
         flags = (_lib.EXPORT_DENSE_NORMALS if dense_normals else 0) | (_lib.EXPORT_INDEXED_PLY if indexed_ply else 0) | \
-            (_lib.EXPORT_STL_NORMALS if stl_normals else 0)
+            (_lib.EXPORT_STL_NORMALS if stl_normals else 0) | (_lib.EXPORT_DENSE_SWEEP if dense_sweep else 0)
         self._ck(self._L.dcsg_export(self._h, export_config_txt.encode(),
                                      None if stl_path is None else os.fsencode(stl_path),
                                      None if ply_path is None else os.fsencode(ply_path), flags, C.byref(st)))

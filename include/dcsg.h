@@ -71,6 +71,10 @@ typedef struct dcsg_export_stats {
     double t_bbox, t_sweep, t_mesh, t_project, t_download, t_write_stl, t_write_ply, t_total;
     /* device time of the lattice sweep kernel(s), milliseconds (HIP events) */
     double sweep_kernel_ms;
+    /* lattice points actually evaluated by the sweep: lattice_points for a dense sweep, fewer for the node-wise
+     * sweep (nodes x (2^(grid-min)+1)^3, shared faces counted per node) */
+    uint64_t swept_points;
+    uint64_t swept_nodes;      /* 0 for a dense sweep */
 } dcsg_export_stats;
 
 /* ---- life cycle ------------------------------------------------------------------- */
@@ -163,6 +167,7 @@ int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* 
  * stl_path / ply_path may be NULL to skip a writer.  flags: DCSG_EXPORT_*. */
 #define DCSG_EXPORT_DENSE_NORMALS 1u  /* sweep normals for every lattice point instead of on demand */
 #define DCSG_EXPORT_SPARSE_NORMALS 2u /* never sweep normals densely (default: dense only for culled scenes) */
+#define DCSG_EXPORT_DENSE_SWEEP 16u   /* sweep the whole lattice even where the node-wise sweep would do */
 #define DCSG_EXPORT_INDEXED_PLY 4u    /* ply_path gets dcsg_write_ply_indexed instead of the reference layout */
 #define DCSG_EXPORT_STL_NORMALS 8u    /* stl_path gets dcsg_write_stl_normals instead of zero normals */
 int dcsg_export(dcsg_ctx* ctx, const char* export_config_txt, const char* stl_path, const char* ply_path,

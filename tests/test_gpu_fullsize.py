@@ -63,6 +63,26 @@ def test_full_size_export_matches_golden(ev, key, tmp_path):
         assert os.path.getsize(tmp_path / "o.ply") == 249 + 85 * len(got) == 33632029
 
 
+@pytest.mark.parametrize("name", ["design2", "flat256"])
+def test_node_wise_sweep_equals_dense_sweep_at_512(ev, name):
+    """dcsg_export sweeps the lattice only inside the octree nodes that are alive at level max(min,2) (default);
+    sweeping every lattice point instead must give the same triangles, the same per-level statistics, and evaluate
+    several times more points."""
+    s = read_scene(name)
+    assert ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
+    cfg_txt = export_config_text(name, levels=[6, 8, 9], gd=3)
+    a = ev.export(cfg_txt)
+    ta = tri_set_hash(ev.download_triangles())
+    b = ev.export(cfg_txt, dense_sweep=True)
+    tb = tri_set_hash(ev.download_triangles())
+    assert a.triangles == b.triangles and ta == tb
+    for f in ("culled", "subdivided", "leaves", "triangles"):
+        assert list(getattr(a.mesh, f)) == list(getattr(b.mesh, f)), f
+    assert b.swept_nodes == 0 and b.swept_points == b.lattice_points == 513 ** 3
+    assert a.swept_nodes == 8 * a.mesh.subdivided[5] and a.swept_points == a.swept_nodes * 9 ** 3
+    assert a.swept_points * 2 < b.swept_points
+
+
 def test_dense_and_on_demand_normals_agree_at_512(ev):
     s = read_scene("design2")
     assert ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
