@@ -1333,12 +1333,15 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
             float mag = dcsg_sqrt(P.hd[0] * P.hd[0] + P.hd[1] * P.hd[1] + P.hd[2] * P.hd[2]);
             culled = __builtin_fabsf(d) > mag * 1.1f;
             if (!culled) {
-                // mesh.hpp:176-183
+                // mesh.hpp:176-183; the corner case is only ever used by a leaf, and a node above the minimum level
+                // is always subdivided (mesh.hpp:214-217), so its corners are not sampled
+                if (P.level >= P.min_level) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    float p[3];
-                    dcsg_corner(k, 1.0f, c, P.hd, p);
-                    lookup |= (sample_sdf(S, p) < 0.0f ? 1u : 0u) << k;
+                    for (int k = 0; k < 8; k++) {
+                        float p[3];
+                        dcsg_corner(k, 1.0f, c, P.hd, p);
+                        lookup |= (sample_sdf(S, p) < 0.0f ? 1u : 0u) << k;
+                    }
                 }
                 bool subdivide = false;
                 if (P.level < P.min_level) {  // mesh.hpp:214-217
