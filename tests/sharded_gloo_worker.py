@@ -68,7 +68,7 @@ def main():
     cfg = parse_export_config(cfg_txt)
     backend = OracleCheckerBackend(scene_dir, table)
     res = sharded.sharded_export(backend, cfg, rank, world, dense_normals=(os.environ.get("DENSE") == "1"),
-                                 check_halo=True)
+                                 check_halo=True, host_staged=(os.environ.get("DENSE") == "1"))  # both transports
     assert backend.halo_checked
     json.dump({"rank": rank, "slab": res["slab"], "counts": res["counts"]}, open(os.path.join(out_dir, "r%d.json" % rank), "w"))
     if rank == 0:
