@@ -93,6 +93,38 @@ KERNEL_VARIANT = {0: "dcsg_sweep", 1: "dcsg_sweep_s4", 2: "dcsg_sweep_s8",
 SDF_ONLY_KERNEL = {3: "dcsg_sweep_sp"}   # SDF-only sweeps of specialised scenes take the one-plane kernel
 
 
+def export_wall_clock(ev):
+    """Second half of BASELINE.json's metric: export wall-clock seconds, scene files on disk -> .stl and .ply closed
+    (dcsg_export), for Design2 at 512^3 and 1024^3 (BASELINE configs 3 and 4) on this one GPU.  Outside the timed
+    region of the headline number; best of three, the first of which creates the files."""
+    import tempfile
+    d = os.path.join(ROOT, "tests", "golden", "scenes", "design2")
+    status, log = ev.build_from_dir(d)
+    if status != 0:
+        return {"error": log[-400:]}
+    lines = open(os.path.join(d, "exportConfig.txt")).read().split("\n")
+    out = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for levels in ((6, 8, 9), (7, 9, 10)):
+            lines[1:4] = [str(v) for v in levels]
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                st = ev.export("\n".join(lines), os.path.join(tmp, "o.stl"), os.path.join(tmp, "o.ply"))
+                wall = time.perf_counter() - t0
+                if best is None or wall < best[0]:
+                    best = (wall, st)
+            wall, st = best
+            out.append({"config": "Design2 levels %d/%d/%d (%d^3 voxels)" % (levels + (1 << levels[2],)),
+                        "seconds": round(wall, 4), "triangles": int(st.triangles),
+                        "stl_bytes": os.path.getsize(os.path.join(tmp, "o.stl")),
+                        "ply_bytes": os.path.getsize(os.path.join(tmp, "o.ply")),
+                        "stage_ms": {k: round(getattr(st, "t_" + k) * 1e3, 2)
+                                     for k in ("bbox", "sweep", "mesh", "project", "download", "write_stl", "write_ply")},
+                        "lattice_points_evaluated": int(st.swept_points), "lattice_points": int(st.lattice_points)})
+    return out
+
+
 def profiled_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the committed PMC summaries (profiles/<tag>_pmc_summary.json:
     separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this same command, FETCH_SIZE doubled as
@@ -118,6 +150,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sphere512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-export", action="store_true", help="skip the export wall-clock lines (second half of the metric)")
     ap.add_argument("--verify-halo", action="store_true", help="after the timed loop, check the received halo plane")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = one workload-sized lattice box per rank, stacked along z (default); "
@@ -306,6 +339,8 @@ def main():
         if tr:
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_source"] = tr[1]
+        if world == 1 and not args.no_export:
+            out["export_wall_clock"] = export_wall_clock(ev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_dir, center, diameter, res)
         print(json.dumps(out))
