@@ -4,10 +4,12 @@ Bar (floating point): north_star states ".stl diff within 1e-5"; these tests hol
 the stricter bar of bit equality with the oracle wherever both pin the arithmetic (IEEE, no
 contraction, correctly rounded sqrt/divide), and state 1e-5 where files are compared.
 """
+import os
+
 import numpy as np
 import pytest
 
-from conftest import export_config_text, read_scene, scene_dir
+from conftest import ROOT, export_config_text, read_scene, scene_dir
 
 pytestmark = pytest.mark.gpu
 
@@ -123,6 +125,33 @@ def test_preview_image_equals_oracle(ev, oracle, name):
         assert ev.build(s["scene.txt"], s["buildprocedure.txt"], None)[0] == 0
         cam = _camera(0.0, 0.0, 15.0)
         assert np.array_equal(ev.render_preview(*cam), osc.render_preview(*cam))
+
+
+def test_headless_run_export_and_preview(oracle, tmp_path):
+    """python -m designcsg_amd.run design.py --export PREFIX --preview IMAGE: File>Run + File>Export of the GUI,
+    headless, in a fresh process (own front-end -> scene files -> libdcsg_hip)."""
+    import subprocess
+    import sys
+    design = os.path.join(ROOT, "tests", "designs", "mixed_groups.py")
+    r = subprocess.run([sys.executable, "-m", "designcsg_amd.run", design, "--workdir", str(tmp_path / "wd"),
+                        "--export", str(tmp_path / "out"), "--preview", str(tmp_path / "view.ppm")],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "exported" in r.stdout
+    osc = oracle.Scene.from_dir(str(tmp_path / "wd"))
+    cfg = oracle.parse_export_config((tmp_path / "wd" / "exportConfig.txt").read_text())
+    c, d, _ = osc.estimate_bounding_box(cfg.bounding_box_half_diameter)
+    table = oracle.LookupTable(open(os.path.join(ROOT, "designcsg_amd", "data", "lookupTable.txt")).read())
+    raw, _ = osc.get_surface(c, d[0], cfg, table)
+    want = osc.gradient_descent(raw, cfg.gradient_descent_steps)
+    stl = (tmp_path / "out.stl").read_bytes()
+    assert len(stl) == 84 + 50 * len(want) and os.path.getsize(tmp_path / "out.ply") > 85 * len(want)
+    got = np.frombuffer(stl[84:], dtype=np.uint8).reshape(-1, 50)[:, 12:48].copy().view(np.float32).reshape(-1, 3, 3)
+    assert np.array_equal(sorted_tris(got[:, :, [0, 2, 1]]), sorted_tris(want))     # the STL stores (x, z, y)
+    ppm = (tmp_path / "view.ppm").read_bytes()
+    assert ppm.startswith(b"P6\n640 480\n255\n") and len(ppm) == 15 + 640 * 480 * 3
+    img = np.frombuffer(ppm[15:], dtype=np.uint8).reshape(480, 640, 3)
+    assert np.array_equal(img, osc.render_preview([0, 0, -15], [1, 0, 0], [0, 1, 0], [0, 0, 1]))
 
 
 def test_builtin_bank_equals_jit_bank(ev, oracle):
