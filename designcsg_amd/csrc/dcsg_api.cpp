@@ -774,7 +774,7 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             unsigned char* d_mask = (unsigned char*)c->d_node_mask.p;
             int lvl = level, sh = shift;
             void* args[] = {(void*)&blob, &nv, &P.lat, (void*)&d_list, &n_nodes, &sh, &lvl, (void*)&ns->d_sdf, (void*)&ns->d_nrm,
-                            (void*)&d_mask};
+                            (void*)&d_mask, &P.hd[0], &P.hd[1], &P.hd[2]};
             HIPCHK(c, hipEventRecord(c->ev0, s));
             if ((r = launch(c, c->k->sweep_nodes[c->variant], n_nodes, DCSG_BLOCK, c->scene.lds_bytes(), s, args))) return r;
             HIPCHK(c, hipEventRecord(c->ev1, s));
@@ -1310,8 +1310,9 @@ int dcsg_export(dcsg_ctx* c, const char* cfg_txt, const char* stl_path, const ch
         if ((r = mesh_impl(c, st.box_center, diameter, &cfg, nullptr, nullptr, 0, res, 0, res, &n_tris, &st.mesh, c->stream, &ns)))
             return r;
         st.sweep_kernel_ms = ns.ms;
-        st.swept_points = ns.points;
-        st.swept_nodes = ns.nodes;
+        // candidates the cull rule dropped are not swept; they are exactly the nodes counted as culled at that level
+        st.swept_nodes = ns.nodes - st.mesh.culled[ns.level];
+        st.swept_points = ns.nodes ? ns.points / ns.nodes * st.swept_nodes : 0;
         st.t_sweep = ns.ms * 1e-3;
         st.t_mesh = now_s() - t0 - st.t_sweep;
     } else {

@@ -935,30 +935,52 @@ DCSG_SWEEP_KERNEL(dcsg_sweep_sp, -1)
 // lattice points; one block per node, points shared with a neighbour are written by both (same bits).  The node's
 // index on the level's grid comes from its snapped centre; node_mask records it for dcsg_lattice_point_written.
 // ---------------------------------------------------------------------------
+// i0: first lattice index of node n per axis; ic: the lattice point its centre snaps to (what the mesher's cull test
+// samples, mesh.hpp:167); slot: the node's byte in node_mask.
 __device__ __forceinline__ void dcsg_node_origin(const DcsgLattice& L, const float* __restrict__ nodes, unsigned int n, int shift,
-                                                 int level, unsigned char* __restrict__ node_mask, int (&i0)[3])
+                                                 int level, int (&i0)[3], int (&ic)[3], size_t& slot)
 {
     const int N = 1 << level;
     int a[3];
     for (int k = 0; k < 3; k++) {
-        a[k] = dcsg_snap(L, k, nodes[(size_t)n * 3 + k]) >> shift;
+        ic[k] = dcsg_snap(L, k, nodes[(size_t)n * 3 + k]);
+        a[k] = ic[k] >> shift;
         a[k] = a[k] > N - 1 ? N - 1 : a[k];
         i0[k] = a[k] << shift;
     }
-    if (threadIdx.x == 0) node_mask[((size_t)a[2] * N + (size_t)a[1]) * N + (size_t)a[0]] = 1;
+    slot = ((size_t)a[2] * N + (size_t)a[1]) * N + (size_t)a[0];
+}
+// The cull rule of mesh.hpp:167-170 on the value at the node's snapped centre: a node it drops is not swept (the
+// mesher then samples that one point on demand and drops the node itself).
+__device__ __forceinline__ bool dcsg_node_culled(float d, float hx, float hy, float hz)
+{
+    float mag = dcsg_sqrt(hx * hx + hy * hy + hz * hz);
+    return __builtin_fabsf(d) > mag * 1.1f;
 }
 
 template <int K>
 __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ blob, int n_vec4, const DcsgLattice& L,
                                                       const float* __restrict__ nodes, unsigned int n_nodes, int shift, int level,
                                                       float* __restrict__ sdf_out, float* __restrict__ nrm_out,
-                                                      unsigned char* __restrict__ node_mask)
+                                                      unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     const unsigned int n1 = (unsigned int)L.res + 1u, side = (1u << shift) + 1u, pts = side * side * side;
     for (unsigned int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
-        int i0[3];
-        dcsg_node_origin(L, nodes, n, shift, level, node_mask, i0);
+        int i0[3], ic[3];
+        size_t slot;
+        dcsg_node_origin(L, nodes, n, shift, level, i0, ic, slot);
+        {   // every lane evaluates the same point: uniform, no divergence
+            float cx = dcsg_lattice_coord(L, 0, ic[0]), cy = dcsg_lattice_coord(L, 1, ic[1]), cz = dcsg_lattice_coord(L, 2, ic[2]);
+            float d, u0, u1, u2;
+            if (K == 0) d = dcsg_primary_sdf(s, cx, cy, cz);
+#ifdef DCSG_HAVE_SPEC
+            else if (K < 0) dcsg_stencil_spec<true>(cx, cy, cz, true, false, d, u0, u1, u2);
+#endif
+            else dcsg_stencil<(K <= 0 ? 4 : K)>(s, cx, cy, cz, true, false, d, u0, u1, u2);
+            if (dcsg_node_culled(d, hdx, hdy, hdz)) continue;
+        }
+        if (threadIdx.x == 0) node_mask[slot] = 1;
         for (unsigned int p = threadIdx.x; p < pts; p += DCSG_BLOCK) {
             unsigned int lz = p / (side * side), r = p - lz * side * side, ly = r / side, lx = r - ly * side;
             unsigned int ix = (unsigned int)i0[0] + lx, iy = (unsigned int)i0[1] + ly, iz = (unsigned int)i0[2] + lz;
@@ -990,9 +1012,10 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
     extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                         \
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,                 \
          unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,       \
-         unsigned char* __restrict__ node_mask)                                                                      \
+         unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz)                                     \
     {                                                                                                                \
-        dcsg_sweep_nodes_body<K>(blob, n_vec4, L, nodes, n_nodes, shift, level, sdf_out, nrm_out, node_mask);        \
+        dcsg_sweep_nodes_body<K>(blob, n_vec4, L, nodes, n_nodes, shift, level, sdf_out, nrm_out, node_mask, hdx,    \
+                                 hdy, hdz);                                                                          \
     }
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes, 0)
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_s4, 4)
@@ -1756,14 +1779,15 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,
                     unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,
-                    unsigned char* __restrict__ node_mask)
+                    unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     const unsigned int n1 = (unsigned int)L.res + 1u, side = (1u << shift) + 1u, pts = side * side * side;
     const float pad = nrm_out ? (float)K2_NORMAL_EPSILON * 1.01f : 0.0f;
     for (unsigned int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
-        int i0[3];
-        dcsg_node_origin(L, nodes, n, shift, level, node_mask, i0);
+        int i0[3], ic[3];
+        size_t slot;
+        dcsg_node_origin(L, nodes, n, shift, level, i0, ic, slot);
         float lo[3], hi[3];
         for (int k = 0; k < 3; k++) {
             lo[k] = dcsg_lattice_coord(L, k, i0[k]);
@@ -1774,6 +1798,13 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
         float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
         const unsigned short* list;
         int n_list = dcsg_build_block_list(s, n_vec4, 0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2]), R, list);
+        {   // cull rule on the snapped centre (inside the node's box, so the node's list serves it); uniform
+            float d, u0, u1, u2;
+            dcsg_stencil<4>(s, dcsg_lattice_coord(L, 0, ic[0]), dcsg_lattice_coord(L, 1, ic[1]), dcsg_lattice_coord(L, 2, ic[2]),
+                            true, false, d, u0, u1, u2, list, n_list);
+            if (dcsg_node_culled(d, hdx, hdy, hdz)) continue;
+        }
+        if (threadIdx.x == 0) node_mask[slot] = 1;
         for (unsigned int p0 = 0; p0 < pts; p0 += DCSG_BLOCK) {
             unsigned int p = p0 + threadIdx.x;
             bool valid = p < pts;
