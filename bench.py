@@ -139,7 +139,8 @@ def profiled_traffic(kernel, workload):
         except (OSError, ValueError):
             continue
         if b.get("config", {}).get("workload") == workload and kernel in pmc and "hbm_bytes_per_launch" in pmc[kernel]:
-            best = (pmc[kernel]["hbm_bytes_per_launch"]["total"], "profiles/" + os.path.basename(f))
+            best = (pmc[kernel]["hbm_bytes_per_launch"]["total"], "profiles/" + os.path.basename(f),
+                    pmc[kernel]["counters_mean_per_launch"].get("SQ_INSTS_VALU"))
     return best
 
 
@@ -339,6 +340,15 @@ def main():
         if tr:
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_source"] = tr[1]
+            if tr[2]:
+                # what actually bounds the kernel: wave64 VALU instructions issued per launch (PMC,
+                # same profile) against 256 CU x 4 SIMD x one instruction per 4 cycles at the 2.4 GHz peak clock
+                peak = 256 * 4 * 2.4e9 / 4
+                rate = tr[2] / (kernel_ms * 1e-3)
+                out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": tr[2],
+                                                 "per_lattice_point": round(tr[2] * 64 / own_points, 1),
+                                                 "achieved_per_s": round(rate, 0), "peak_per_s": peak,
+                                                 "frac": round(rate / peak, 4)}
         if world == 1 and not args.no_export:
             out["export_wall_clock"] = export_wall_clock(ev)
         if world == 1 and not args.no_cpu_baseline:
