@@ -113,8 +113,15 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
                       row(k, u, "u").c_str(), row(k, f, "f").c_str(), brush);
                 }
             }
+            // `simplify` scenes: right after "PUSH null brush" the accumulator is the constant MAX_DISTANCE and the value
+            // joined to it cannot be NaN (standard brushes, finite coordinates), so T_min(64, r) = (64 < r ? 64 : r) is
+            // the IEEE minimum: one v_min_f32 instead of compare + select.  Same value for every non-NaN r.
+            const bool acc_is_max_distance = simplify && op == ACC_MIN && c > 0 && s.stack_prog[4 * (c - 1)] == PUSH &&
+                                             (s.stack_prog[4 * (c - 1) + 1] & 0xff) == 0 && null_brush_const &&
+                                             s.stack_prog[4 * (c - 1) + 3] == depth - 1;
             for (int k = 0; k < N; k++) {
                 if (op == PUSH) P("    s%d_%d = r%d;\n", depth, k, k);
+                else if (acc_is_max_distance) P("    s%d_%d = __builtin_fminf(r%d, (float)MAX_DISTANCE);\n", depth - 1, k, k);
                 else if (op == ACC_MIN) P("    s%d_%d = s%d_%d < r%d ? s%d_%d : r%d;\n", depth - 1, k, depth - 1, k, k, depth - 1, k, k);
                 else if (op == ACC_MAX) P("    s%d_%d = s%d_%d > r%d ? s%d_%d : r%d;\n", depth - 1, k, depth - 1, k, k, depth - 1, k, k);
                 else if (op == ACC_NEGMAX) P("    { const float nb = -r%d; s%d_%d = s%d_%d > nb ? s%d_%d : nb; }\n", k, depth - 1, k, depth - 1, k, depth - 1, k);
