@@ -536,7 +536,7 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     if (const char* force = getenv("DCSG_FORCE_VARIANT")) {  // A/B testing only; never exceeds what the program fits
         int f = atoi(force);
         if (f == 0 || (f == 1 && depth <= 4) || (f == 2 && depth <= 8)) c->variant = f;
-        if (f == 4 && c->variant != 4) c->variant = c->variant;  // culling is only ever chosen by the rule above
+        // f == 4: culling is only ever chosen by the rule above
     }
     c->scene_loaded = true;
     c->n_tris = 0;
