@@ -266,6 +266,32 @@ def test_mesher_and_projection_bit_exact(ev, oracle, lookup_table, name, dense_n
     assert np.max(np.abs(v - w)) <= STL_TOL
 
 
+@pytest.mark.parametrize("levels", [(5, 5, 5), (2, 4, 6), (1, 3, 5), (6, 6, 7), (3, 6, 6), (2, 2, 7), (4, 5, 9)])
+@pytest.mark.parametrize("name", ["mixed_groups", "design1"])
+def test_level_combinations(ev, oracle, lookup_table, name, levels):
+    """Octree level triples around the switches of dcsg_export: node-wise sweep at level max(min,2) with nodes of
+    2, 3, 5, 9 and 17 points per axis, min below 2, min = max = grid, and (2,2,7) / (4,5,9), where nodes would be 33
+    points wide and the dense sweep is used instead.  Mesh and per-level statistics against the oracle."""
+    load(ev, name)
+    cfg_txt = export_config_text(name, levels=levels, gd=4)
+    st = ev.export(cfg_txt)
+    got = ev.download_triangles()
+    osc = oracle.Scene.from_dir(scene_dir(name))
+    ocfg = oracle.parse_export_config(cfg_txt)
+    oc, od, _ = osc.estimate_bounding_box(ocfg.bounding_box_half_diameter)
+    raw, ost = osc.get_surface(oc, od[0], ocfg, lookup_table)
+    want = osc.gradient_descent(raw, 4)
+    assert st.triangles == len(want)
+    for l in range(16):
+        assert st.mesh.culled[l] == ost.nodes_culled[l] and st.mesh.subdivided[l] == ost.nodes_subdivided[l]
+        assert st.mesh.triangles[l] == ost.triangles[l]
+    assert np.array_equal(sorted_tris(got), sorted_tris(want))
+    node_wise = levels[2] - max(levels[0], 2) <= 4
+    assert (st.swept_nodes > 0) == node_wise
+    if not node_wise:
+        assert st.swept_points == st.lattice_points
+
+
 def test_projection_without_lattice(ev, oracle):
     load(ev, "design2")
     import torch
