@@ -1566,6 +1566,35 @@ dcsg_mesh_emit(DcsgMeshParams P, const float* __restrict__ nodes, unsigned int n
 // a vertex run in registers: 12 B read + 12 B written per vertex for the whole loop instead of
 // the reference's 100 blocking evaluator round trips.
 // ---------------------------------------------------------------------------
+// performGradientDescent (mesh.hpp:531-593) iterates p <- F(p) = p - sdf(p) * normal(p), a pure function of the
+// position's bits, a fixed number of times.  Once F(p) == p bit for bit the remaining steps cannot change anything;
+// once F(F(p)) == p the positions alternate and the last one follows from the parity of the steps that are left.
+// Both are detected per vertex and the vertex is retired with exactly the position the full iteration would end
+// on; a wave stops when all its vertices are retired (after a handful of steps: projection onto a distance field
+// converges fast, then the update falls below half an ulp of the coordinates).
+struct DcsgDescent {
+    float x, y, z;        // current position p_k
+    float px, py, pz;     // p_(k-1)
+    bool have_prev, done;
+};
+__device__ __forceinline__ bool dcsg_same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
+// q = F(p_k) was just computed as step number k (0-based) of `steps`
+__device__ __forceinline__ void dcsg_descent_advance(DcsgDescent& d, float qx, float qy, float qz, int k, int steps)
+{
+    if (d.done) return;
+    if (dcsg_same_bits(qx, d.x) && dcsg_same_bits(qy, d.y) && dcsg_same_bits(qz, d.z)) {
+        d.done = true;  // fixed point: p stays
+    } else if (d.have_prev && dcsg_same_bits(qx, d.px) && dcsg_same_bits(qy, d.py) && dcsg_same_bits(qz, d.pz)) {
+        // period two: after this step the position is q = p_(k-1); each further step flips between q and p_k
+        if (((steps - 1 - k) & 1) == 0) d.x = qx, d.y = qy, d.z = qz;
+        d.done = true;
+    } else {
+        d.px = d.x, d.py = d.y, d.pz = d.z;
+        d.x = qx, d.y = qy, d.z = qz;
+        d.have_prev = true;
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void dcsg_project_body(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ verts,
                                                   unsigned int n_verts, int steps)
@@ -1575,8 +1604,10 @@ __device__ __forceinline__ void dcsg_project_body(const uint4* __restrict__ blob
     for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         unsigned int i = tile * DCSG_BLOCK + threadIdx.x;
         if (i >= n_verts) continue;
-        float x = verts[(size_t)i * 3 + 0], y = verts[(size_t)i * 3 + 1], z = verts[(size_t)i * 3 + 2];
+        DcsgDescent d = {verts[(size_t)i * 3 + 0], verts[(size_t)i * 3 + 1], verts[(size_t)i * 3 + 2], 0.0f, 0.0f, 0.0f, false, false};
         for (int k = 0; k < steps; k++) {
+            if (__builtin_amdgcn_ballot_w64(!d.done) == 0ull) break;
+            const float x = d.x, y = d.y, z = d.z;
             float sd, nx, ny, nz;
             if (K == 0) {
                 sd = dcsg_primary_sdf(s, x, y, z);
@@ -1589,13 +1620,11 @@ __device__ __forceinline__ void dcsg_project_body(const uint4* __restrict__ blob
                 dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, true, true, sd, nx, ny, nz);
             }
             float m = -sd;  // v3f_scale(n, -s) then v3f_add, CVector.cpp:128-149
-            x = x + m * nx;
-            y = y + m * ny;
-            z = z + m * nz;
+            dcsg_descent_advance(d, x + m * nx, y + m * ny, z + m * nz, k, steps);
         }
-        verts[(size_t)i * 3 + 0] = x;
-        verts[(size_t)i * 3 + 1] = y;
-        verts[(size_t)i * 3 + 2] = z;
+        verts[(size_t)i * 3 + 0] = d.x;
+        verts[(size_t)i * 3 + 1] = d.y;
+        verts[(size_t)i * 3 + 2] = d.z;
     }
 }
 
@@ -1840,20 +1869,21 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
         unsigned int i = tile * DCSG_BLOCK + threadIdx.x;
         bool valid = i < n_verts;
         unsigned int j = valid ? i : 0u;
-        float x = verts[(size_t)j * 3 + 0], y = verts[(size_t)j * 3 + 1], z = verts[(size_t)j * 3 + 2];
+        DcsgDescent d = {verts[(size_t)j * 3 + 0], verts[(size_t)j * 3 + 1], verts[(size_t)j * 3 + 2], 0.0f, 0.0f, 0.0f, false, !valid};
         for (int k = 0; k < steps; k++) {
-            int n_list = dcsg_build_active_list(s, valid, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list);
+            if (__builtin_amdgcn_ballot_w64(!d.done) == 0ull) break;
+            // the tile is the box of the vertices that are still moving; retired lanes run along and are ignored
+            const float x = d.x, y = d.y, z = d.z;
+            int n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list);
             float sd, nx, ny, nz;
             dcsg_stencil<4>(s, x, y, z, true, true, sd, nx, ny, nz, list, n_list);
             float m = -sd;
-            x = x + m * nx;
-            y = y + m * ny;
-            z = z + m * nz;
+            dcsg_descent_advance(d, x + m * nx, y + m * ny, z + m * nz, k, steps);
         }
         if (valid) {
-            verts[(size_t)i * 3 + 0] = x;
-            verts[(size_t)i * 3 + 1] = y;
-            verts[(size_t)i * 3 + 2] = z;
+            verts[(size_t)i * 3 + 0] = d.x;
+            verts[(size_t)i * 3 + 1] = d.y;
+            verts[(size_t)i * 3 + 2] = d.z;
         }
     }
 }
