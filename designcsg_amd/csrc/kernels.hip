@@ -1386,19 +1386,27 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
                             }
                         }
                     }
-                    // complex edges, mesh.hpp:244-258 (angleBetweenVectors, geometry.hpp:118-124)
-                    for (int e = 0; e < 12 && !subdivide; e++) {
-                        float a[3], b[3], na[3], nb[3];
-                        dcsg_corner(dcsg_edge_a(e), 1.0f, c, P.hd, a);
-                        dcsg_corner(dcsg_edge_b(e), 1.0f, c, P.hd, b);
-                        sample_normal(S, a, na);
-                        sample_normal(S, b, nb);
-                        float ma = dcsg_sqrt(na[0] * na[0] + na[1] * na[1] + na[2] * na[2]);
-                        float mb = dcsg_sqrt(nb[0] * nb[0] + nb[1] * nb[1] + nb[2] * nb[2]);
-                        if (!(ma * mb < 1e-6f)) {
-                            float q = (na[0] * nb[0] + na[1] * nb[1] + na[2] * nb[2]) / (ma * mb);
-                            // (float)acos((double)q) > threshold, folded by the host into q_star
-                            if (q >= -1.0f && q <= P.q_star) subdivide = true;
+                    // complex edges, mesh.hpp:244-258 (angleBetweenVectors, geometry.hpp:118-124).  The reference samples
+                    // the normal at both ends of each of the 12 edges; those are the 8 corners, three times each, so
+                    // they are sampled once (an on-demand normal is six evaluations of the scene).
+                    if (!subdivide) {
+                        float cn[8][3], cm[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            float p[3];
+                            dcsg_corner(k, 1.0f, c, P.hd, p);
+                            sample_normal(S, p, cn[k]);
+                            cm[k] = dcsg_sqrt(cn[k][0] * cn[k][0] + cn[k][1] * cn[k][1] + cn[k][2] * cn[k][2]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 12; e++) {
+                            const int ia = dcsg_edge_a(e), ib = dcsg_edge_b(e);
+                            float mm = cm[ia] * cm[ib];
+                            if (!(mm < 1e-6f)) {
+                                float q = (cn[ia][0] * cn[ib][0] + cn[ia][1] * cn[ib][1] + cn[ia][2] * cn[ib][2]) / mm;
+                                // (float)acos((double)q) > threshold, folded by the host into q_star
+                                if (q >= -1.0f && q <= P.q_star) subdivide = true;
+                            }
                         }
                     }
                 }
