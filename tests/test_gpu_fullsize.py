@@ -63,14 +63,15 @@ def test_full_size_export_matches_golden(ev, key, tmp_path):
         assert os.path.getsize(tmp_path / "o.ply") == 249 + 85 * len(got) == 33632029
 
 
-@pytest.mark.parametrize("name", ["design2", "flat256"])
-def test_node_wise_sweep_equals_dense_sweep_at_512(ev, name):
+@pytest.mark.parametrize("name,levels", [("design2", (6, 8, 9)), ("flat256", (6, 8, 9)), ("flat256", (5, 7, 9)),
+                                         ("smooth256", (6, 8, 9)), ("grouped256", (5, 8, 9))])
+def test_node_wise_sweep_equals_dense_sweep_at_512(ev, name, levels):
     """dcsg_export sweeps the lattice only inside the octree nodes that are alive at level max(min,2) (default);
     sweeping every lattice point instead must give the same triangles, the same per-level statistics, and evaluate
-    several times more points."""
+    several times more points.  Nodes of 9^3 and 17^3 points; specialised, culling and smooth-join kernels."""
     s = read_scene(name)
     assert ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
-    cfg_txt = export_config_text(name, levels=[6, 8, 9], gd=3)
+    cfg_txt = export_config_text(name, levels=list(levels), gd=3)
     a = ev.export(cfg_txt)
     ta = tri_set_hash(ev.download_triangles())
     b = ev.export(cfg_txt, dense_sweep=True)
@@ -79,8 +80,10 @@ def test_node_wise_sweep_equals_dense_sweep_at_512(ev, name):
     for f in ("culled", "subdivided", "leaves", "triangles"):
         assert list(getattr(a.mesh, f)) == list(getattr(b.mesh, f)), f
     assert b.swept_nodes == 0 and b.swept_points == b.lattice_points == 513 ** 3
-    assert a.swept_nodes == 8 * a.mesh.subdivided[5] - a.mesh.culled[6] and a.swept_points == a.swept_nodes * 9 ** 3
-    assert a.swept_points * 4 < b.swept_points
+    m = levels[0]
+    side = (1 << (9 - m)) + 1
+    assert a.swept_nodes == 8 * a.mesh.subdivided[m - 1] - a.mesh.culled[m] and a.swept_points == a.swept_nodes * side ** 3
+    assert a.swept_points * 3 < b.swept_points
 
 
 def test_dense_and_on_demand_normals_agree_at_512(ev):
