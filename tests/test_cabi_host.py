@@ -3,6 +3,7 @@ declares, fails loudly without a GPU, and its host logic (parsers, writers, look
 build-procedure optimiser, brush JIT) agrees with the oracle.  No kernel is launched here."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -381,6 +382,32 @@ def test_smooth_extension_hand_written(built_lib, oracle):
     for bad in ("0 2 1 0\n0 3 2 1\n6 0 1 0\n1 0 -1 -1", "8 0 0 0\n1 0 -1 -1", "8 -1082130432 0 0\n1 0 -1 -1",
                 "8 2143289344 0 0\n1 0 -1 -1", "8 2139095040 0 0\n1 0 -1 -1"):
         assert compile_program(built_lib, scene_txt, bad)[0] != 0, bad
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_program_optimiser_on_random_designs(built_lib, oracle, seed, tmp_path):
+    """Generated designs (tests/designs/random_tree.py: every group kind, smooth joins, carved leaves, nesting): the
+    host's fused register program and its stack program, run in numpy float32, equal the oracle's interpretation of
+    the buildprocedure.txt the front-end wrote, bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "designs"))
+    try:
+        from random_tree import make_script
+    finally:
+        sys.path.pop(0)
+    from designcsg_amd.run import run_design
+    script = tmp_path / "design.py"
+    script.write_text(make_script(2000 + seed, big=(seed % 2 == 1)))
+    wd = run_design(str(script), str(tmp_path / "wd"))
+    sc = {f: open(os.path.join(wd, f)).read() for f in ("scene.txt", "buildprocedure.txt", "scene.cl")}
+    sc["dir"] = wd
+    rc, reg, n_regs, stk, depth = compile_program(built_lib, sc["scene.txt"], sc["buildprocedure.txt"])
+    assert rc == 0 and len(stk) > 0 and 1 <= depth <= 3
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(-4, 4, (4000, 3)).astype(np.float32)
+    want = oracle.Scene.from_dir(wd).eval_sdf(pts)
+    imp = object_values(oracle, sc, pts)
+    assert np.array_equal(run_register_program(reg, n_regs, imp, len(pts)).view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(run_stack_program(stk, imp, len(pts)).view(np.uint32), want.view(np.uint32))
 
 
 def test_scene_validation(built_lib):

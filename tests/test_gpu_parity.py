@@ -154,6 +154,60 @@ def test_headless_run_export_and_preview(oracle, tmp_path):
     assert np.array_equal(img, osc.render_preview([0, 0, -15], [1, 0, 0], [0, 1, 0], [0, 0, 1]))
 
 
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_scenes(ev, oracle, lookup_table, seed, tmp_path, monkeypatch):
+    """Differential test on generated designs (tests/designs/random_tree.py: every group kind, smooth joins, carved
+    leaves, nesting, axis-aligned objects at the origin): the scene the own front-end compiles is evaluated on every
+    device path the scene is eligible for and exported; everything must equal the oracle bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "designs"))
+    try:
+        from random_tree import make_script
+    finally:
+        sys.path.pop(0)
+    from designcsg_amd.run import run_design
+    script = tmp_path / "design.py"
+    script.write_text(make_script(1000 + seed, big=(seed % 3 == 2)))
+    wd = run_design(str(script), str(tmp_path / "wd"))
+    osc = oracle.Scene.from_dir(wd)
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(-4.5, 4.5, (30_000, 3)).astype(np.float32)
+    pts[:3] = [(0, 0, 0), (-0.0, 0.0, 1.0), (2.5, -0.0, -0.0)]
+    want_s, want_n = osc.eval_sdf(pts), osc.eval_normal(pts)
+    seen = set()
+    for env in ({}, {"DCSG_SPECIALISE": "0"}, {"DCSG_SPECIALISE": "0", "DCSG_CULL": "0"},
+                {"DCSG_SPECIALISE": "0", "DCSG_CULL": "0", "DCSG_FORCE_VARIANT": "0"}, {"DCSG_NO_SIMPLIFY": "1"}):
+        for k in ("DCSG_SPECIALISE", "DCSG_CULL", "DCSG_FORCE_VARIANT", "DCSG_NO_SIMPLIFY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert ev.build_from_dir(wd)[0] == 0
+        seen.add(ev.scene_info()["interpreter"])
+        assert np.array_equal(bits(ev.eval_sdf_at_points(pts)), bits(want_s)), env
+        assert np.array_equal(bits(ev.eval_normal_at_points(pts)), bits(want_n)), env
+    assert 0 in seen and len(seen) >= 2
+    for k in ("DCSG_SPECIALISE", "DCSG_CULL", "DCSG_FORCE_VARIANT", "DCSG_NO_SIMPLIFY"):
+        monkeypatch.delenv(k, raising=False)
+    assert ev.build_from_dir(wd)[0] == 0
+    cfg_txt = open(os.path.join(wd, "exportConfig.txt")).read()
+    ocfg = oracle.parse_export_config(cfg_txt)
+    oc, od, on = osc.estimate_bounding_box(ocfg.bounding_box_half_diameter)
+    if not od[0] > 0:
+        return          # nothing solid in the probe cube
+    gs, gn = ev.eval_lattice(oc, od[0], 24)
+    ws, wn = osc.eval_lattice(oc, od[0], 24)
+    assert np.array_equal(bits(gs), bits(ws)) and np.array_equal(bits(gn), bits(wn))
+    for dense in (False, True):
+        st = ev.export(cfg_txt, dense_sweep=dense, dense_normals=dense)
+        assert list(st.box_center) == oc and st.box_diameter == od[0] and st.interior_points == on
+        raw, ost = osc.get_surface(oc, od[0], ocfg, lookup_table)
+        want = osc.gradient_descent(raw, ocfg.gradient_descent_steps)
+        assert st.triangles == len(want)
+        assert np.array_equal(sorted_tris(ev.download_triangles()), sorted_tris(want))
+        for l in range(16):
+            assert st.mesh.culled[l] == ost.nodes_culled[l] and st.mesh.subdivided[l] == ost.nodes_subdivided[l]
+
+
 def test_builtin_bank_equals_jit_bank(ev, oracle):
     """scene.cl = None selects the HIP-native brushes; the generated scene.cl text must agree with them."""
     s = read_scene("flat256")
