@@ -315,11 +315,37 @@ __device__ __forceinline__ float dcsg_primary_sdf(const SceneLds& s, float x, fl
     return export_value;
 }
 
+// n / d exactly as the compiler's IEEE-754 division sequence computes it once v_div_scale_f32 and v_div_fixup_f32
+// are no-ops -- which they are for normal operands away from the ends of the exponent range (here: 2^-60 <= |n|,
+// d <= 2^60 and |n| <= 2 d, so quotient and reciprocal are normal too): r1 is the refined reciprocal, then two
+// residual corrections of the quotient.  Same instructions, same bits; the reciprocal is shared by the three
+// components (tools/fast_div_probe.hip: 1.3e10 operand pairs against `/`, no difference).
+__device__ __forceinline__ float dcsg_div_by(float n, float d, float r1)
+{
+    float q = n * r1;
+    float e2 = __builtin_fmaf(-d, q, n);
+    float q1 = __builtin_fmaf(e2, r1, q);
+    float e3 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(e3, r1, q1);
+}
+
 // OpenCL normalize(float3) pinned as v / length(v), zero vector stays zero.
 __device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
 {
     float len = dcsg_sqrt(x * x + y * y + z * z);
-    if (len == 0.0f) {
+    const float lo = 0x1p-60f, hi = 0x1p60f;
+    // components are at most len (1 + 2^-22) in magnitude; a zero, tiny, huge or NaN operand anywhere in the wave
+    // sends the wave through the plain divisions (zero components: lattice points on a symmetry plane)
+    const bool plain = !(len >= lo && len <= hi && __builtin_fabsf(x) >= lo && __builtin_fabsf(y) >= lo &&
+                         __builtin_fabsf(z) >= lo);
+    if (__builtin_amdgcn_ballot_w64(plain) == 0ull) {
+        float r = __builtin_amdgcn_rcpf(len);
+        float e = __builtin_fmaf(-len, r, 1.0f);
+        float r1 = __builtin_fmaf(e, r, r);
+        x = dcsg_div_by(x, len, r1);
+        y = dcsg_div_by(y, len, r1);
+        z = dcsg_div_by(z, len, r1);
+    } else if (len == 0.0f) {
         x = y = z = 0.0f;
     } else {
         x = x / len;
