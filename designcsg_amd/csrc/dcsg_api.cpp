@@ -1004,6 +1004,13 @@ bool pwrite_all(int fd, const unsigned char* buf, size_t bytes, off_t off)
 // free and re-allocate every page-cache page of the old file, which costs more than writing the bytes (C4: 36 ms
 // against 12 ms for the 136 MB .ply).
 int open_for_overwrite(const char* path) { return open(path, O_WRONLY | O_CREAT, 0644); }
+// Reserve the final size before the parallel pwrites (a new file: block allocation once instead of per extension,
+// C4 .ply 13.0 -> 10.5 ms on overlayfs).  fallocate(2) itself, not posix_fallocate: a file system without support
+// answers EOPNOTSUPP and nothing is lost, where glibc's emulation would write every block.
+void reserve_file(int fd, off_t size)
+{
+    if (size > 0 && !getenv("DCSG_NO_FALLOCATE")) (void)fallocate(fd, 0, 0, size);
+}
 bool finish_file(int fd, off_t size, bool ok)
 {
     if (ftruncate(fd, size) != 0) ok = false;
@@ -1028,6 +1035,7 @@ int dcsg_write_stl(const char* path, const float* tris, uint64_t n)
     if (!path || (n && !tris)) return DCSG_ERR_INVALID;
     int fd = open_for_overwrite(path);
     if (fd < 0) return DCSG_ERR_IO;
+    reserve_file(fd, (off_t)(84 + n * 50));
     unsigned char head[84];
     memset(head, 0, sizeof(head));
     uint32_t n32 = (uint32_t)n;
@@ -1066,6 +1074,7 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
                       (unsigned long long)(n * 3), (unsigned long long)n);
     int fd = open_for_overwrite(path);
     if (fd < 0) return DCSG_ERR_IO;
+    reserve_file(fd, (off_t)hl + (off_t)(n * 85));
     bool ok = pwrite_all(fd, (const unsigned char*)header, (size_t)hl, 0);
     const off_t verts_at = hl, faces_at = hl + (off_t)(n * 72);
     ok = ok && parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
@@ -1100,6 +1109,7 @@ int dcsg_write_stl_normals(const char* path, const float* tris, uint64_t n)
     if (!path || (n && !tris)) return DCSG_ERR_INVALID;
     int fd = open_for_overwrite(path);
     if (fd < 0) return DCSG_ERR_IO;
+    reserve_file(fd, (off_t)(84 + n * 50));
     unsigned char head[84];
     memset(head, 0, sizeof(head));
     uint32_t n32 = (uint32_t)n;
@@ -1176,6 +1186,7 @@ int dcsg_write_ply_indexed(const char* path, const float* tris, uint64_t n, uint
                       (unsigned long long)nv, (unsigned long long)n);
     int fd = open_for_overwrite(path);
     if (fd < 0) return DCSG_ERR_IO;
+    reserve_file(fd, (off_t)hl + (off_t)(nv * 12 + n * 13));
     bool ok = pwrite_all(fd, (const unsigned char*)header, (size_t)hl, 0);
     ok = ok && pwrite_all(fd, (const unsigned char*)verts.data(), (size_t)nv * 12, hl);
     const off_t faces_at = hl + (off_t)(nv * 12);
