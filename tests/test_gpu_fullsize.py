@@ -86,6 +86,24 @@ def test_node_wise_sweep_equals_dense_sweep_at_512(ev, name, levels):
     assert a.swept_points * 3 < b.swept_points
 
 
+def test_sphere_at_2048_cubed(ev):
+    """One size beyond BASELINE.json's largest (grid level 11: a 2049^3 lattice, 8.6 G points, 34 GB if dense).  No
+    oracle run exists at this size; the domain's own invariants do: every projected vertex lies on the sphere of
+    radius 2.5 to 1e-5, the triangle count scales with the area (4x the 1024^3 count to within 1 %), and the
+    node-wise sweep touches a fraction of the lattice."""
+    s = read_scene("sphere")
+    assert ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
+    st = ev.export(export_config_text("sphere", levels=[8, 10, 11], gd=50))
+    assert st.lattice_points == 2049 ** 3 and st.box_diameter == 5.3515625
+    assert 0 < st.swept_points < st.lattice_points // 5
+    t10 = ev.export(export_config_text("sphere", levels=[7, 9, 10], gd=0)).triangles
+    assert abs(st.triangles / (4.0 * t10) - 1.0) < 0.01
+    st = ev.export(export_config_text("sphere", levels=[8, 10, 11], gd=50))
+    v = ev.download_triangles().reshape(-1, 3).astype(np.float64)
+    r = np.linalg.norm(v, axis=1)
+    assert len(v) == 3 * st.triangles and abs(r.mean() - 2.5) < 1e-6 and np.abs(r - 2.5).max() < 1e-5
+
+
 def test_dense_and_on_demand_normals_agree_at_512(ev):
     s = read_scene("design2")
     assert ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
