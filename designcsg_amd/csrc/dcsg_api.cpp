@@ -1240,6 +1240,8 @@ int dcsg_jit_prebuild_scene(const char* scene_txt, const char* bp_txt, const cha
     return rc;
 }
 
+float dcsg_angle_q_star(float complex_surface_threshold) { return angle_threshold_to_q_star(complex_surface_threshold); }
+
 int dcsg_compile_program(const char* scene_txt, const char* bp_txt, int32_t* reg_prog, int* n_reg_steps, int* n_regs,
                          int32_t* stack_prog, int* n_stack_steps, int* stack_depth, int cap)
 {

@@ -187,6 +187,9 @@ int dcsg_compile_program(const char* scene_txt, const char* buildprocedure_txt, 
 /* lookupTable.txt expanded as the kernels see it: table[case*16] = triangle count, then 3 edge ids per
  * triangle (cms::getIndexTrianglesFromTable + getIndexTriangleStrip). */
 int dcsg_expand_lookup_table(const char* lookup_table_txt, uint8_t table[4096], int* total_triangles);
+/* Diagnostic: the fold of mesh.hpp:253 `angleBetweenVectors(a,b) > threshold` (geometry.hpp:118-124) into one compare:
+ * the largest float q with (float)acos((double)q) > threshold, or -2 if there is none. */
+float dcsg_angle_q_star(float complex_surface_threshold);
 
 /* Diagnostic: the kernels' correctly rounded square root over a device array (exhaustive GPU test). */
 int dcsg_debug_sqrt_device(dcsg_ctx* ctx, const float* d_in, size_t n, float* d_out, void* stream);

@@ -55,6 +55,21 @@ def build(force=False):
     return LIB
 
 
+REFERENCE = "/root/reference/master"
+REF_LIB = os.path.join(HERE, "_ref", "libdcsg_ref.so")
+
+
+def build_ref(force=False):
+    """oracle/_ref: the parts of the REAL reference that compile on their own (ref_shim.cpp), where the reference
+    tree is present (the build container; the built file travels to the GPU box).  Returns the path or None."""
+    if not os.path.isdir(REFERENCE):
+        return REF_LIB if os.path.exists(REF_LIB) else None
+    shim = os.path.join(HERE, "ref_shim.cpp")
+    if force or not os.path.exists(REF_LIB) or os.path.getmtime(REF_LIB) < os.path.getmtime(shim):
+        subprocess.run(["make", "-C", HERE, "-s", "ref"], check=True)
+    return REF_LIB
+
+
 def scene_bank_path(scene_cl_text):
     h = hashlib.sha256(scene_cl_text.encode()).hexdigest()[:16]
     return os.path.join(BUILD, "scene_%s.so" % h)
