@@ -29,6 +29,44 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert sorted(_lib.PROTOTYPES) == names, "ctypes prototypes and include/dcsg.h disagree"
 
 
+def test_header_is_plain_c_and_a_c_program_links(built_lib, tmp_path):
+    """include/dcsg.h is the boundary a maintainer binds: it must compile as C99 and as C++, and a
+    C program linked against libdcsg_hip.so must get the documented behaviour without a GPU (dcsg_create fails with
+    DCSG_ERR_NO_DEVICE and a message; the host-only entry points work)."""
+    import subprocess
+    from designcsg_amd import build as b
+    src = tmp_path / "client.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "dcsg.h"
+int main(void) {
+    dcsg_ctx* ctx = NULL;
+    int rc = dcsg_create(&ctx, 0);
+    dcsg_export_config cfg;
+    int rc2 = dcsg_parse_export_config("10.0\n6\n8\n9\n0.785\n50\n16\n512\n4096\n", &cfg);
+    float tri[9] = {0, 0, 0, 1, 0, 0, 0, 1, 0};
+    int rc3 = dcsg_write_stl("one.stl", tri, 1);
+    printf("%d|%s|%d|%d|%d|%d\n", rc, dcsg_last_error(NULL), rc2, cfg.grid_level, cfg.gradient_descent_steps, rc3);
+    if (ctx) dcsg_destroy(ctx);
+    return 0;
+}
+''')
+    inc = os.path.join(ROOT, "include")
+    for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++17", "c++")):
+        subprocess.run([cc, std, "-x", lang, "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I" + inc, str(src)], check=True)
+    exe = tmp_path / "client"
+    subprocess.run(["gcc", "-std=c99", "-I" + inc, str(src), "-o", str(exe), "-L" + b.OUT, "-ldcsg_hip",
+                    "-Wl,-rpath," + b.OUT, "-Wl,-rpath," + os.path.join(b.ROCM, "lib")], check=True)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="")
+    r = subprocess.run([str(exe)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rc, msg, rc2, grid, gd, rc3 = r.stdout.strip().split("|")
+    assert int(rc) == -2 and "no CPU fallback" in msg          # DCSG_ERR_NO_DEVICE, loudly
+    assert (int(rc2), int(grid), int(gd), int(rc3)) == (0, 9, 50, 0)
+    assert os.path.getsize(tmp_path / "one.stl") == 84 + 50
+
+
 def test_no_symbol_of_the_oracle_is_linked(built_lib):
     import subprocess
     from designcsg_amd import _lib
