@@ -1249,8 +1249,8 @@ int dcsg_compile_program(const char* scene_txt, const char* bp_txt, int32_t* reg
     std::string err;
     if (!parse_scene(scene_txt, bp_txt, s, err)) return fail(nullptr, DCSG_ERR_INVALID, err);
     if (s.n_prog > cap || s.n_stack_prog > cap) return fail(nullptr, DCSG_ERR_INVALID, "output arrays too small");
-    if (reg_prog) memcpy(reg_prog, s.prog.data(), s.prog.size() * sizeof(int32_t));
-    if (stack_prog) memcpy(stack_prog, s.stack_prog.data(), s.stack_prog.size() * sizeof(int32_t));
+    if (reg_prog && !s.prog.empty()) memcpy(reg_prog, s.prog.data(), s.prog.size() * sizeof(int32_t));
+    if (stack_prog && !s.stack_prog.empty()) memcpy(stack_prog, s.stack_prog.data(), s.stack_prog.size() * sizeof(int32_t));
     if (n_reg_steps) *n_reg_steps = s.n_prog;
     if (n_regs) *n_regs = s.n_regs;
     if (n_stack_steps) *n_stack_steps = s.n_stack_prog;
