@@ -87,10 +87,74 @@ def cpu_baseline(scene_dir, center, diameter, res, budget_s=15.0):
                       "%d points, %.1f s)" % (planes, n1, planes / n1, n1, pts, dt)}
 
 
-# kernel that a fused SDF+normal sweep launches, by interpreter variant (dcsg_api.cpp: sweep_device)
-KERNEL_VARIANT = {0: "dcsg_sweep", 1: "dcsg_sweep_s4", 2: "dcsg_sweep_s8",
-                  3: "dcsg_sweep_sp" if os.environ.get("DCSG_NO_PLANE_PAIRS") else "dcsg_sweep_sp2", 4: "dcsg_sweep_c4"}
-SDF_ONLY_KERNEL = {3: "dcsg_sweep_sp"}   # SDF-only sweeps of specialised scenes take the one-plane kernel
+# kernel that a fused SDF+normal sweep launches, by interpreter variant (dcsg_api.cpp: sweep_device); the SDF-only
+# sweep launches the `_d` instantiation of the same kernel
+KERNEL_VARIANT = {0: "dcsg_sweep_f", 1: "dcsg_sweep_s4_f", 2: "dcsg_sweep_s8_f", 3: "dcsg_sweep_sp_f", 4: "dcsg_sweep_c4"}
+SDF_ONLY_KERNEL = {0: "dcsg_sweep_d", 1: "dcsg_sweep_s4_d", 2: "dcsg_sweep_s8_d", 3: "dcsg_sweep_sp_d", 4: "dcsg_sweep_c4"}
+
+
+def time_sweeps(ev, center, diameter, res, reps=10):
+    """Device time (HIP events on the launch stream) of the fused and of the SDF-only sweep of the whole lattice with the
+    scene currently loaded in `ev`.  Secondary lines only: outside the timed region of the headline number."""
+    import ctypes as C
+    import torch
+    from designcsg_amd import _lib
+    L, h = _lib.lib(), ev._h
+    n1 = res + 1
+    sdf = torch.empty(n1 ** 3, dtype=torch.float32, device="cuda")
+    nrm = torch.empty(3 * n1 ** 3, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    c3, d3, sp = (C.c_float * 3)(*center), (C.c_float * 3)(diameter, diameter, diameter), C.c_void_p(stream.cuda_stream)
+    out = {}
+    for key, nptr in (("fused", nrm.data_ptr()), ("sdf_only", None)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(reps + 2):
+            if i == 2:
+                e0.record(stream)
+            rc = L.dcsg_sweep_lattice_device(h, c3, d3, res, 0, n1, C.c_void_p(sdf.data_ptr()), C.c_void_p(nptr) if nptr else None, sp)
+            if rc:
+                _lib.check(h, rc)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        bytes_ = (16 if nptr else 4) * n1 ** 3
+        out[key] = {"kernel_ms": round(ms, 4), "GB_per_s": round(bytes_ / (ms * 1e-3) / 1e9, 1),
+                    "frac_of_hbm_peak": round(bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "Mvoxels_per_s": round(res ** 3 / (ms * 1e-3) / 1e6, 1)}
+    del sdf, nrm
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_sweeps(scene_dir, device, center, diameter, res):
+    """N=1 only, outside the timed region: the same workload through (a) the LDS-table stack interpreter north_star
+    describes (`_s4` kernels: op / object tables staged in LDS, no per-scene code), (b) the opt-in relaxed-numerics
+    module (NOT bit-exact; tests/test_gpu_relaxed.py bounds it), and (c) the exact default at 1024^3, the other lattice
+    size BASELINE.json's metric is quoted on."""
+    from designcsg_amd.evaluator import Evaluator
+    out = {}
+    os.environ["DCSG_SPECIALISE"] = "0"
+    try:
+        ev = Evaluator(device)
+        assert ev.build_from_dir(scene_dir)[0] == 0
+        k = ev.scene_info()["interpreter"]
+        out["lds_table_interpreter"] = dict(time_sweeps(ev, center, diameter, res), kernel=KERNEL_VARIANT[k], numerics="exact")
+        ev.close()
+    finally:
+        os.environ.pop("DCSG_SPECIALISE", None)
+    ev = Evaluator(device)
+    ev.set_numerics("relaxed")
+    assert ev.build_from_dir(scene_dir)[0] == 0
+    out["relaxed_numerics"] = dict(time_sweeps(ev, center, diameter, res), kernel=KERNEL_VARIANT[ev.scene_info()["interpreter"]],
+                                   numerics="relaxed (opt-in: hardware sqrt/rsq, FMA contraction; within 1e-5, not bit-exact)")
+    out["relaxed_numerics_1024"] = dict(time_sweeps(ev, center, diameter, 2 * res, reps=5), numerics="relaxed", lattice_points=(2 * res + 1) ** 3)
+    ev.close()
+    ev = Evaluator(device)
+    assert ev.build_from_dir(scene_dir)[0] == 0
+    out["exact_1024"] = dict(time_sweeps(ev, center, diameter, 2 * res, reps=5), kernel=KERNEL_VARIANT[ev.scene_info()["interpreter"]],
+                             numerics="exact", lattice_points=(2 * res + 1) ** 3)
+    ev.close()
+    return out
 
 
 def export_wall_clock(ev):
@@ -151,6 +215,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sphere512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary sweep lines (LDS-table interpreter, "
+                    "relaxed numerics, 1024^3)")
     ap.add_argument("--no-export", action="store_true", help="skip the export wall-clock lines (second half of the metric)")
     ap.add_argument("--verify-halo", action="store_true", help="after the timed loop, check the received halo plane")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -349,6 +415,8 @@ def main():
                                                  "per_lattice_point": round(tr[2] * 64 / own_points, 1),
                                                  "achieved_per_s": round(rate, 0), "peak_per_s": peak,
                                                  "frac": round(rate / peak, 4)}
+        if world == 1 and not args.no_secondary:
+            out["secondary_sweeps"] = secondary_sweeps(scene_dir, local_rank, center, diameter, res)
         if world == 1 and not args.no_export:
             out["export_wall_clock"] = export_wall_clock(ev)
         if world == 1 and not args.no_cpu_baseline:

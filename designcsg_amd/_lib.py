@@ -53,6 +53,7 @@ PROTOTYPES = {
     "dcsg_last_error": (C.c_char_p, [C.c_void_p]),
     "dcsg_load_scene": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "dcsg_set_arbitrary_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dcsg_set_numerics": (C.c_int, [C.c_void_p, C.c_int]),
     "dcsg_scene_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 6),
     "dcsg_eval_sdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dcsg_eval_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -76,6 +77,8 @@ PROTOTYPES = {
     "dcsg_render_preview": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dcsg_write_stl": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
     "dcsg_write_ply": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
+    "dcsg_write_stl_range": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint]),
+    "dcsg_write_ply_range": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint]),
     "dcsg_write_stl_normals": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64]),
     "dcsg_write_ply_indexed": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "dcsg_parse_export_config": (C.c_int, [C.c_char_p, C.POINTER(ExportConfig)]),
@@ -89,6 +92,8 @@ PROTOTYPES = {
     "dcsg_jit_prebuild_scene": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t,
                                           C.POINTER(C.c_int)]),
     "dcsg_jit_prebuild": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "dcsg_jit_prebuild_scene_numerics": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t,
+                                                   C.POINTER(C.c_int)]),
 }
 
 _lib = None

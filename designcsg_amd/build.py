@@ -2,6 +2,7 @@
 
   dcsg_builtin.hsaco        kernels.hip with the HIP-native built-in brush bank (code object)
   dcsg_kernels_extern.bc    kernels.hip as device bitcode, linked against a scene.cl at load time
+  dcsg_kernels_relaxed.bc   the same with the opt-in relaxed arithmetic (dcsg_set_numerics)
   libdcsg_hip.so            the C ABI (include/dcsg.h): host side + comgr JIT
   jitcache/*.hsaco          per-scene code objects compiled ahead of time (optional warm-up)
 
@@ -25,6 +26,7 @@ ARCH = "gfx950"
 DEVICE_FLAGS = ["--offload-arch=" + ARCH, "--cuda-device-only", "-O3", "-ffp-contract=off", "-fno-slp-vectorize",
                 "-std=c++17"]
 LIB = os.path.join(OUT, "libdcsg_hip.so")
+RELAXED_SCENES = ("sphere", "design2", "design1")
 
 
 def _newer(target, sources):
@@ -68,6 +70,12 @@ def build(verbose=False, prebuild_scenes=True):
         for f in glob.glob(os.path.join(OUT, "jitcache", "*.hsaco")):
             os.remove(f)
 
+    # opt-in relaxed numerics (dcsg_set_numerics): same kernels, FMA contraction allowed, DCSG_RELAXED arithmetic
+    bcr = os.path.join(OUT, "dcsg_kernels_relaxed.bc")
+    if _newer(bcr, dev_deps):
+        flags = [f for f in DEVICE_FLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast"]
+        _run([HIPCC] + flags + ["-fgpu-rdc", "-emit-llvm", "-DDCSG_EXTERN_BANK", "-DDCSG_RELAXED", "-c", kernels, "-o", bcr])
+
     _embed_cl()
     host_src = [os.path.join(CSRC, f) for f in ("dcsg_api.cpp", "scene.cpp", "jit.cpp", "specialise.cpp")]
     host_deps = host_src + glob.glob(os.path.join(CSRC, "*.h*")) + \
@@ -102,6 +110,16 @@ def prebuild_jit_cache(verbose=False):
             if verbose:
                 print("jit", os.path.relpath(d), "specialise<=" + spec, "cached" if cached.value else "compiled")
     os.environ.pop("DCSG_SPECIALISE", None)
+    # the relaxed-numerics modules of the scenes tests/test_gpu_relaxed.py and bench.py load
+    lib.dcsg_jit_prebuild_scene_numerics.argtypes = [ctypes.c_char_p] * 3 + [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
+                                                                             ctypes.POINTER(ctypes.c_int)]
+    for name in RELAXED_SCENES:
+        d = os.path.join(HERE, "..", "tests", "golden", "scenes", name)
+        rd = lambda n: open(os.path.join(d, n), "rb").read()
+        log = ctypes.create_string_buffer(1 << 16)
+        rc = lib.dcsg_jit_prebuild_scene_numerics(rd("scene.txt"), rd("buildprocedure.txt"), rd("scene.cl"), 1, log, len(log), None)
+        if rc != 0:
+            raise RuntimeError("relaxed JIT of %s failed:\n%s" % (name, log.value.decode(errors="replace")))
 
 
 if __name__ == "__main__":

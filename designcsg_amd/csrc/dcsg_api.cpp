@@ -38,7 +38,7 @@ struct DevBuf {
 struct Kernels {
     hipFunction_t sweep[5] = {}, eval_points[5] = {}, bbox[5] = {}, project[5] = {};
     hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr;
-    hipFunction_t sweep_sp2 = nullptr;  // specialised sweep, two planes per thread (scene modules only)
+    hipFunction_t sweep_d[4] = {}, sweep_f[4] = {};  // sweep[v] with the outputs fixed at compile time: SDF only / SDF + normals
     hipFunction_t sweep_nodes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // node-wise sweep per variant
     hipFunction_t dd_insert = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
 };
@@ -65,6 +65,8 @@ struct dcsg_ctx {
     Kernels kb, ks;       // built-in bank / scene module
     Kernels* k = nullptr;  // active
     bool scene_loaded = false, jit = false, specialised = false;
+    int numerics = 0;  // DCSG_NUMERICS_EXACT / _RELAXED for the scenes loaded from now on (dcsg_set_numerics)
+    bool scene_relaxed = false;
     int variant = 0;  // index into Kernels::sweep[] etc., chosen from the scene's register count
     Scene scene;
     std::vector<float> ad_host;
@@ -138,6 +140,8 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
         } tab[] = {{"dcsg_sweep", &k.sweep[v]}, {"dcsg_eval_points", &k.eval_points[v]}, {"dcsg_bbox", &k.bbox[v]},
                    {"dcsg_project", &k.project[v]}, {"dcsg_sweep_nodes", &k.sweep_nodes[v]}};
         for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, (std::string(t.name) + suffix[v]).c_str()));
+        HIPCHK(c, hipModuleGetFunction(&k.sweep_d[v], mod, (std::string("dcsg_sweep") + suffix[v] + "_d").c_str()));
+        HIPCHK(c, hipModuleGetFunction(&k.sweep_f[v], mod, (std::string("dcsg_sweep") + suffix[v] + "_f").c_str()));
     }
     struct {
         const char* name;
@@ -156,7 +160,6 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
     }
     if (scene_module) {
         HIPCHK(c, hipModuleGetFunction(&k.set_ad, mod, "dcsg_set_arbitrary_data"));
-        HIPCHK(c, hipModuleGetFunction(&k.sweep_sp2, mod, "dcsg_sweep_sp2"));
     }
     return 0;
 }
@@ -193,20 +196,22 @@ DcsgLattice make_lattice(const float center[3], const float diam[3], int res)
 
 unsigned sweep_grid(const dcsg_ctx* c, unsigned tiles)
 {
-    unsigned cap = (unsigned)c->n_cu * 32u;  // 8 resident 256-thread blocks per CU, x4 for tail balance
+    static const int per_cu = getenv("DCSG_BLOCKS_PER_CU") ? atoi(getenv("DCSG_BLOCKS_PER_CU")) : 32;
+    unsigned cap = (unsigned)c->n_cu * (unsigned)(per_cu > 0 ? per_cu : 32);  // 8 resident 256-thread blocks per CU, x4 for tail balance
     return tiles < cap ? tiles : cap;
 }
 
 // How a scene's code object is obtained: the stand-alone module with the HIP-native brush bank, or a
 // module compiled from its scene.cl (+ the generated specialisation of its build procedure).
 struct ModulePlan {
-    bool needs_jit = false, specialise = false, null0 = true;
+    bool needs_jit = false, specialise = false, null0 = true, relaxed = false;
     std::string cl, extra;
 };
 
-bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std::string& err)
+bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std::string& err, bool relaxed = false)
 {
     p.cl = scene_cl ? scene_cl : "";
+    p.relaxed = relaxed;
     bool builtin_only;  // every brush in use is one of sd0..sd4 with its standard body
     if (!scene_cl) {
         if (s.max_brush_id > 4) {
@@ -227,7 +232,7 @@ bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std:
     const char* env_spec = getenv("DCSG_SPECIALISE");  // max object evaluations to specialise; 0 disables
     int spec_limit = env_spec ? atoi(env_spec) : 48;
     p.specialise = s.n_stack_prog > 0 && n_evals <= spec_limit;
-    p.needs_jit = !(builtin_only && !p.specialise);
+    p.needs_jit = !(builtin_only && !p.specialise) || relaxed;  // the relaxed arithmetic exists as a scene module only
     if (p.needs_jit) {
         if (builtin_only) p.cl = builtin_scene_cl();
         p.null0 = builtin_only || scene_cl_null_brush_is_const(p.cl);
@@ -299,24 +304,35 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     const void* blob = c->d_blob.p;
     int nv = c->scene.blob_vec4();
     if (time_it) HIPCHK(c, hipEventRecord(c->ev0, s));
-    // launches cover whole planes (an even number of them), < 2^30 points each
+    // launches cover whole planes, < 2^30 points each
     const uint64_t plane = n1 * n1;
     uint64_t planes_per = (1ull << 30) / plane;
-    planes_per = planes_per < 2 ? 1 : (planes_per & ~1ull);
-    const bool pairs = c->variant == 3 && d_nrm != nullptr && !getenv("DCSG_NO_PLANE_PAIRS");
-    hipFunction_t fn = pairs ? c->k->sweep_sp2 : c->k->sweep[c->variant];
+    planes_per = planes_per < 1 ? 1 : planes_per;
+    // kernels with the outputs fixed at compile time where they exist (SDF only / SDF + normals)
+    hipFunction_t fn = c->k->sweep[c->variant];
+    if (c->variant < 4 && d_sdf) fn = d_nrm ? c->k->sweep_f[c->variant] : c->k->sweep_d[c->variant];
+    // per-axis coordinate tables behind the scene's LDS area (kernels.hip, "Wave-level lattice indexing"); a lattice
+    // too large for them (or with rows shorter than a wave) takes the per-lane index path
+    size_t lds = (c->scene.lds_bytes() + 15) & ~(size_t)15;
+    int axes_off = -1;
+    if (n1 >= DCSG_WAVE && lds + 3 * n1 * sizeof(float) <= 160 * 1024 && c->variant != 4 && !getenv("DCSG_NO_AXIS_TABLES")) {
+        axes_off = (int)lds;
+        lds += 3 * n1 * sizeof(float);
+    }
     for (uint64_t p0 = 0; p0 < (uint64_t)(z1 - z0); p0 += planes_per) {
         uint64_t np = (uint64_t)(z1 - z0) - p0 < planes_per ? (uint64_t)(z1 - z0) - p0 : planes_per;
         unsigned first = (unsigned)(p0 * plane);
         unsigned cnt = (unsigned)(np * plane);
-        unsigned work = pairs ? (unsigned)(((np + 1) / 2) * plane) : cnt;
+        unsigned work = cnt;
+        unsigned per_block = 4u * DCSG_BLOCK;  // a block covers 4 runs of 256 points per pass (dcsg_sweep_body)
         if (c->variant == 4) {  // 8 x 8 x 4 bricks, one per 256-thread block iteration
             uint64_t b8 = (n1 + 7) / 8;
             work = (unsigned)(b8 * b8 * ((np + 3) / 4) * DCSG_BLOCK);
+            per_block = DCSG_BLOCK;
         }
-        unsigned tiles = (work + DCSG_BLOCK - 1) / DCSG_BLOCK;
-        void* args[] = {(void*)&blob, &nv, &L, &z0, &first, &cnt, (void*)&d_sdf, (void*)&d_nrm};
-        int r = launch(c, fn, sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), s, args);
+        unsigned tiles = (work + per_block - 1) / per_block;
+        void* args[] = {(void*)&blob, &nv, &L, &z0, &first, &cnt, (void*)&d_sdf, (void*)&d_nrm, &axes_off};
+        int r = launch(c, fn, sweep_grid(c, tiles), DCSG_BLOCK, lds, s, args);
         if (r) return r;
     }
     if (time_it) {
@@ -491,14 +507,14 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     std::string err;
     if (!parse_scene(scene_txt, bp_txt, s, err)) return fail(c, DCSG_ERR_INVALID, err);
     ModulePlan plan;
-    if (!plan_scene_module(s, scene_cl, plan, err)) return fail(c, DCSG_ERR_INVALID, err);
+    if (!plan_scene_module(s, scene_cl, plan, err, c->numerics == DCSG_NUMERICS_RELAXED)) return fail(c, DCSG_ERR_INVALID, err);
     if (!plan.needs_jit) {
         build_blob(s, true);
         c->k = &c->kb;
         c->jit = false;
     } else {
         std::string hsaco, log;
-        if (!jit_scene_module(plan.cl, plan.extra, hsaco, log, nullptr))
+        if (!jit_scene_module(plan.cl, plan.extra, hsaco, log, nullptr, plan.relaxed))
             return fail(c, DCSG_ERR_BUILD, "Error when building evaluation program:\n" + log);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->scene_mod) {
@@ -513,6 +529,7 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
         c->jit = true;
     }
     c->specialised = c->jit && plan.specialise;
+    c->scene_relaxed = plan.relaxed;
     // every kernel stages the scene tables in LDS: they must fit one workgroup's share (160 KiB on gfx950)
     if (s.lds_bytes() > 160 * 1024)
         return fail(c, DCSG_ERR_INVALID,
@@ -549,6 +566,14 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     }
     std::fill(c->ad_host.begin(), c->ad_host.end(), 0.0f);
     return dcsg_set_arbitrary_data(c, ad, ad ? n_ad : 0);
+}
+
+int dcsg_set_numerics(dcsg_ctx* c, int mode)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    if (mode != DCSG_NUMERICS_EXACT && mode != DCSG_NUMERICS_RELAXED) return fail(c, DCSG_ERR_INVALID, "unknown numerics mode");
+    c->numerics = mode;
+    return 0;
 }
 
 int dcsg_scene_info(const dcsg_ctx* c, int* n_objects, int* n_steps, int* n_slots, int* jit_compiled, int* interpreter,
@@ -881,14 +906,16 @@ int dcsg_project_triangles(dcsg_ctx* c, int steps, void* stream)
     if (!c) return DCSG_ERR_INVALID;
     const size_t n_verts = (size_t)c->n_tris * 3;
     const char* env = getenv("DCSG_DEDUP");
-    if (steps <= 0 || n_verts < 4096 || n_verts > 0x7fffffffull || (env && atoi(env) == 0))
+    // the hash table has 2^k >= 2 n slots of 32-bit vertex ids: beyond 2^30 vertices the plain projection runs
+    if (steps <= 0 || n_verts < 4096 || n_verts > (1ull << 30) || (env && atoi(env) == 0))
         return dcsg_project_vertices_device(c, (float*)c->d_tris.p, n_verts, steps, stream);
     int r = need_scene(c);
     if (r) return r;
     hipStream_t s = (hipStream_t)stream;
     unsigned n = (unsigned)n_verts, n_blocks = (n + DCSG_BLOCK - 1) / DCSG_BLOCK;
-    unsigned table_size = 1;
-    while (table_size < 2 * n) table_size <<= 1;
+    uint64_t table_size64 = 1;
+    while (table_size64 < 2ull * n) table_size64 <<= 1;  // <= 2^31 for n <= 2^30
+    unsigned table_size = (unsigned)table_size64;
     unsigned mask = table_size - 1;
     if ((r = ensure(c, c->d_dd_table, (size_t)table_size * 4))) return r;
     if ((r = ensure(c, c->d_dd_rep, (size_t)n * 4))) return r;
@@ -1013,7 +1040,7 @@ void reserve_file(int fd, off_t size)
 }
 bool finish_file(int fd, off_t size, bool ok)
 {
-    if (ftruncate(fd, size) != 0) ok = false;
+    if (ftruncate(fd, ok ? size : 0) != 0) ok = false;  // a failed write leaves an empty file, not a plausible one
     return close(fd) == 0 && ok;
 }
 
@@ -1024,24 +1051,27 @@ unsigned writer_threads()
     return n < 1 ? 1u : (n > 64 ? 64u : (unsigned)n);
 }
 
-}  // namespace
+// Crash safety of the in-place writers: a file is valid only between END and the next BEGIN.  BEGIN overwrites the
+// first bytes with a marker no STL / PLY reader accepts as the start of a complete file, the payload follows, and only
+// when every byte is in place is the file cut to its final length and given its real header (END).  A failed export
+// leaves an empty file; an interrupted one a file that starts with the marker -- never a valid header over a stale or
+// partial body.
+static const char kIncomplete[] = "dcsg: incomplete export -- this file was being written when the exporter stopped\n";
 
-extern "C" {
-
-// writeTrianglesToSTL, utils.hpp:41-103: 80 zero bytes, u32 count, per triangle a zero normal, then
-// A, B, C each written as (x, z, y), then u16 0.  Little-endian host assumed (x86-64).
-int dcsg_write_stl(const char* path, const float* tris, uint64_t n)
+int ply_header(char* header, size_t cap, uint64_t n)
 {
-    if (!path || (n && !tris)) return DCSG_ERR_INVALID;
-    int fd = open_for_overwrite(path);
-    if (fd < 0) return DCSG_ERR_IO;
-    reserve_file(fd, (off_t)(84 + n * 50));
-    unsigned char head[84];
-    memset(head, 0, sizeof(head));
-    uint32_t n32 = (uint32_t)n;
-    memcpy(head + 80, &n32, 4);
-    bool ok = pwrite_all(fd, head, sizeof(head), 0);
-    ok = ok && parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
+    return snprintf(header, cap,
+                    "ply\nformat binary_little_endian 1.0\n"
+                    "comment Written with hapPLY (https://github.com/nmwsharp/happly)\n"
+                    "element vertex %llu\nproperty double x\nproperty double y\nproperty double z\n"
+                    "element face %llu\nproperty list uchar uint vertex_indices\nend_header\n",
+                    (unsigned long long)(n * 3), (unsigned long long)n);
+}
+
+// STL payload of triangles [first, first + n) of a file of `total` triangles: records at 84 + 50 t
+bool stl_payload(int fd, const float* tris, uint64_t n, uint64_t first)
+{
+    return parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
         const uint64_t step = 1u << 15;  // triangles per buffer (1.6 MB)
         std::vector<unsigned char> buf((size_t)step * 50);
         for (uint64_t a = t0; a < t1; a += step) {
@@ -1053,31 +1083,19 @@ int dcsg_write_stl(const char* path, const float* tris, uint64_t n)
                 memcpy(o, rec, 48);
                 o[48] = o[49] = 0;
             }
-            if (!pwrite_all(fd, buf.data(), (size_t)(b - a) * 50, (off_t)(84 + a * 50))) return false;
+            if (!pwrite_all(fd, buf.data(), (size_t)(b - a) * 50, (off_t)(84 + (first + a) * 50))) return false;
         }
         return true;
     });
-    return finish_file(fd, (off_t)(84 + n * 50), ok) ? 0 : DCSG_ERR_IO;
 }
 
-// writeTrianglesToPLY, utils.hpp:106-154 via happly.h:1998-2039 (header), 1538-1570 (double x,y,z),
-// 1640-1670 (uchar count + uint indices): un-indexed, vertices as doubles, faces (3i,3i+1,3i+2).
-int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
+// PLY payload of triangles [first, first + n) of a file of `total`: vertices at hl + 72 t, faces at hl + 72 total + 13 t
+bool ply_payload(int fd, const float* tris, uint64_t n, uint64_t first, uint64_t total)
 {
-    if (!path || (n && !tris)) return DCSG_ERR_INVALID;
     char header[512];
-    int hl = snprintf(header, sizeof(header),
-                      "ply\nformat binary_little_endian 1.0\n"
-                      "comment Written with hapPLY (https://github.com/nmwsharp/happly)\n"
-                      "element vertex %llu\nproperty double x\nproperty double y\nproperty double z\n"
-                      "element face %llu\nproperty list uchar uint vertex_indices\nend_header\n",
-                      (unsigned long long)(n * 3), (unsigned long long)n);
-    int fd = open_for_overwrite(path);
-    if (fd < 0) return DCSG_ERR_IO;
-    reserve_file(fd, (off_t)hl + (off_t)(n * 85));
-    bool ok = pwrite_all(fd, (const unsigned char*)header, (size_t)hl, 0);
-    const off_t verts_at = hl, faces_at = hl + (off_t)(n * 72);
-    ok = ok && parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
+    const int hl = ply_header(header, sizeof(header), total);
+    const off_t verts_at = hl, faces_at = hl + (off_t)(total * 72);
+    return parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
         const uint64_t step = 1u << 14;  // triangles per buffer (1.2 MB of vertices, 0.2 MB of faces)
         std::vector<unsigned char> vbuf((size_t)step * 72), fbuf((size_t)step * 13);
         for (uint64_t a = t0; a < t1; a += step) {
@@ -1088,17 +1106,75 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
                 memcpy(o, &v, 8);
             }
             unsigned char* q = fbuf.data();
-            for (uint64_t t = a; t < b; t++, q += 13) {
+            for (uint64_t t = first + a; t < first + b; t++, q += 13) {
                 q[0] = 3;
                 uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
                 memcpy(q + 1, idx, 12);
             }
-            if (!pwrite_all(fd, vbuf.data(), (size_t)(b - a) * 72, verts_at + (off_t)(a * 72))) return false;
-            if (!pwrite_all(fd, fbuf.data(), (size_t)(b - a) * 13, faces_at + (off_t)(a * 13))) return false;
+            if (!pwrite_all(fd, vbuf.data(), (size_t)(b - a) * 72, verts_at + (off_t)((first + a) * 72))) return false;
+            if (!pwrite_all(fd, fbuf.data(), (size_t)(b - a) * 13, faces_at + (off_t)((first + a) * 13))) return false;
         }
         return true;
     });
-    return finish_file(fd, (off_t)hl + (off_t)(n * 85), ok) ? 0 : DCSG_ERR_IO;
+}
+
+// One file format's BEGIN / payload / END (see dcsg_write_stl_range in dcsg.h)
+int write_range(const char* path, const float* tris, uint64_t n, uint64_t first, uint64_t total, unsigned flags, bool ply)
+{
+    if (!path || (n && !tris) || first + n > total) return DCSG_ERR_INVALID;
+    if (!ply && total > 0xffffffffull) return DCSG_ERR_INVALID;      // the STL header holds a 32-bit triangle count
+    if (ply && total * 3 > 0xffffffffull) return DCSG_ERR_INVALID;   // face lists index vertices with 32-bit uints
+    char header[512];
+    int hl = 84;
+    if (ply) {
+        hl = ply_header(header, sizeof(header), total);
+    } else {
+        memset(header, 0, 84);
+        uint32_t n32 = (uint32_t)total;
+        memcpy(header + 80, &n32, 4);
+    }
+    const off_t size = (off_t)hl + (off_t)(total * (ply ? 85 : 50));
+    const bool begin = (flags & DCSG_WRITE_BEGIN) != 0, end = (flags & DCSG_WRITE_END) != 0;
+    int fd = begin ? open_for_overwrite(path) : open(path, O_WRONLY);
+    if (fd < 0) return DCSG_ERR_IO;
+    bool ok = true;
+    if (begin) {
+        ok = pwrite_all(fd, (const unsigned char*)kIncomplete, sizeof(kIncomplete) - 1, 0);
+        reserve_file(fd, size);
+    }
+    if (ok && n) ok = ply ? ply_payload(fd, tris, n, first, total) : stl_payload(fd, tris, n, first);
+    if (ok && end) ok = ftruncate(fd, size) == 0 && pwrite_all(fd, (const unsigned char*)header, (size_t)hl, 0);
+    if (!ok) (void)ftruncate(fd, 0);  // nothing that could pass for a finished file stays behind
+    return close(fd) == 0 && ok ? 0 : DCSG_ERR_IO;
+}
+
+}  // namespace
+
+extern "C" {
+
+// writeTrianglesToSTL, utils.hpp:41-103: 80 zero bytes, u32 count, per triangle a zero normal, then
+// A, B, C each written as (x, z, y), then u16 0.  Little-endian host assumed (x86-64).
+int dcsg_write_stl(const char* path, const float* tris, uint64_t n)
+{
+    return write_range(path, tris, n, 0, n, DCSG_WRITE_BEGIN | DCSG_WRITE_END, false);
+}
+
+// writeTrianglesToPLY, utils.hpp:106-154 via happly.h:1998-2039 (header), 1538-1570 (double x,y,z),
+// 1640-1670 (uchar count + uint indices): un-indexed, vertices as doubles, faces (3i,3i+1,3i+2).
+int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
+{
+    return write_range(path, tris, n, 0, n, DCSG_WRITE_BEGIN | DCSG_WRITE_END, true);
+}
+
+// Byte-range forms for sharded exports ("each rank writes its byte range of the STL/PLY"): both
+// formats are fixed-size records once the total count is known.
+int dcsg_write_stl_range(const char* path, const float* tris, uint64_t n, uint64_t first, uint64_t total, unsigned flags)
+{
+    return write_range(path, tris, n, first, total, flags, false);
+}
+int dcsg_write_ply_range(const char* path, const float* tris, uint64_t n, uint64_t first, uint64_t total, unsigned flags)
+{
+    return write_range(path, tris, n, first, total, flags, true);
 }
 
 // ---- opt-in writers beyond the reference's -----------------------------------------------
@@ -1107,6 +1183,7 @@ int dcsg_write_ply(const char* path, const float* tris, uint64_t n)
 int dcsg_write_stl_normals(const char* path, const float* tris, uint64_t n)
 {
     if (!path || (n && !tris)) return DCSG_ERR_INVALID;
+    if (n > 0xffffffffull) return DCSG_ERR_INVALID;
     int fd = open_for_overwrite(path);
     if (fd < 0) return DCSG_ERR_IO;
     reserve_file(fd, (off_t)(84 + n * 50));
@@ -1221,15 +1298,21 @@ int dcsg_debug_sqrt_device(dcsg_ctx* c, const float* d_in, size_t n, float* d_ou
 int dcsg_jit_prebuild_scene(const char* scene_txt, const char* bp_txt, const char* scene_cl, char* log_out, size_t log_cap,
                              int* from_cache)
 {
+    return dcsg_jit_prebuild_scene_numerics(scene_txt, bp_txt, scene_cl, DCSG_NUMERICS_EXACT, log_out, log_cap, from_cache);
+}
+
+int dcsg_jit_prebuild_scene_numerics(const char* scene_txt, const char* bp_txt, const char* scene_cl, int numerics,
+                                     char* log_out, size_t log_cap, int* from_cache)
+{
     Scene s;
     std::string err, hsaco, log;
     ModulePlan plan;
     bool cached = false;
     int rc = 0;
-    if (!parse_scene(scene_txt, bp_txt, s, err) || !plan_scene_module(s, scene_cl, plan, err)) {
+    if (!parse_scene(scene_txt, bp_txt, s, err) || !plan_scene_module(s, scene_cl, plan, err, numerics == DCSG_NUMERICS_RELAXED)) {
         log = err;
         rc = DCSG_ERR_INVALID;
-    } else if (plan.needs_jit && !jit_scene_module(plan.cl, plan.extra, hsaco, log, &cached)) {
+    } else if (plan.needs_jit && !jit_scene_module(plan.cl, plan.extra, hsaco, log, &cached, plan.relaxed)) {
         rc = DCSG_ERR_BUILD;
     }
     if (from_cache) *from_cache = cached ? 1 : 0;

@@ -59,16 +59,34 @@ struct ComgrApi {
 #undef DCSG_COMGR_FN
 };
 
+// Which compiler builds the code objects: the file libamd_comgr would be loaded from, its size and time stamp (a ROCm
+// upgrade changes at least one of them), so that cached code objects of another compiler are never reused.  Only
+// stat(2): a cache hit must not pay for loading the compiler.
+static std::vector<std::string> comgr_candidates()
+{
+    std::vector<std::string> c;
+    if (const char* e = getenv("DCSG_COMGR_PATH")) c.push_back(e);
+    const char* rocm = getenv("ROCM_PATH");
+    c.push_back(std::string(rocm ? rocm : "/opt/rocm") + "/lib/libamd_comgr.so.3");
+    c.push_back("/opt/rocm/lib/libamd_comgr.so.3");
+    c.push_back("libamd_comgr.so.3");
+    return c;
+}
+static std::string comgr_identity()
+{
+    for (auto& c : comgr_candidates()) {
+        struct stat st;
+        if (stat(c.c_str(), &st) == 0)
+            return c + ":" + std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtime);
+    }
+    return "unknown";
+}
+
 static ComgrApi& comgr()
 {
     static ComgrApi api;
     if (api.handle || !api.error.empty()) return api;
-    std::vector<std::string> candidates;
-    if (const char* e = getenv("DCSG_COMGR_PATH")) candidates.push_back(e);
-    const char* rocm = getenv("ROCM_PATH");
-    candidates.push_back(std::string(rocm ? rocm : "/opt/rocm") + "/lib/libamd_comgr.so.3");
-    candidates.push_back("/opt/rocm/lib/libamd_comgr.so.3");
-    candidates.push_back("libamd_comgr.so.3");
+    std::vector<std::string> candidates = comgr_candidates();
     for (auto& c : candidates) {
         api.handle = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
         if (api.handle) break;
@@ -134,16 +152,48 @@ static bool write_file_atomic(const std::string& path, const std::string& data)
     return rename(tmp.c_str(), path.c_str()) == 0;
 }
 
+// A directory is trusted for cached code objects only if it belongs to this user and nobody else can write to it:
+// whatever lies there is handed to hipModuleLoadData.
+static bool private_dir(const std::string& d)
+{
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    return st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0 && access(d.c_str(), W_OK) == 0;
+}
+
+// DCSG_JIT_CACHE, else <library dir>/jitcache (the in-tree build), else $XDG_CACHE_HOME/dcsg_jitcache or
+// ~/.cache/dcsg_jitcache (mode 0700).  Empty string: no usable directory, the cache is off.
 static std::string cache_dir()
 {
-    const char* env = getenv("DCSG_JIT_CACHE");
-    std::string d = env ? env : library_dir() + "/jitcache";
-    mkdir(d.c_str(), 0777);
-    if (access(d.c_str(), W_OK) != 0) {
-        d = "/tmp/dcsg_jitcache_" + std::to_string((long)getuid());
-        mkdir(d.c_str(), 0777);
+    std::vector<std::string> candidates;
+    if (const char* env = getenv("DCSG_JIT_CACHE")) {
+        candidates.push_back(env);
+    } else {
+        candidates.push_back(library_dir() + "/jitcache");
+        const char* xdg = getenv("XDG_CACHE_HOME");
+        const char* home = getenv("HOME");
+        if (xdg && *xdg) candidates.push_back(std::string(xdg) + "/dcsg_jitcache");
+        else if (home && *home) {
+            mkdir((std::string(home) + "/.cache").c_str(), 0700);
+            candidates.push_back(std::string(home) + "/.cache/dcsg_jitcache");
+        }
     }
-    return d;
+    for (auto& d : candidates) {
+        mkdir(d.c_str(), 0700);
+        if (private_dir(d)) return d;
+    }
+    return "";
+}
+
+// a cached file is loaded only if it is a regular file of this user and looks like a 64-bit little-endian AMDGPU ELF
+static bool read_cached_code_object(const std::string& path, std::string& out)
+{
+    struct stat st;
+    if (lstat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != getuid()) return false;
+    if (!read_file(path, out) || out.size() < 64) return false;
+    const unsigned char* e = (const unsigned char*)out.data();
+    const unsigned machine = e[18] | (e[19] << 8);
+    return e[0] == 0x7f && e[1] == 'E' && e[2] == 'L' && e[3] == 'F' && e[4] == 2 && e[5] == 1 && machine == 224;  // EM_AMDGPU
 }
 
 struct ComgrSet {
@@ -216,16 +266,16 @@ static bool run_action(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, 
 }
 
 bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, std::string& hsaco, std::string& log,
-                      bool* from_cache)
+                      bool* from_cache, bool relaxed)
 {
     if (from_cache) *from_cache = false;
     std::string kernels_bc;
-    std::string bc_path = library_dir() + "/dcsg_kernels_extern.bc";
+    std::string bc_path = library_dir() + (relaxed ? "/dcsg_kernels_relaxed.bc" : "/dcsg_kernels_extern.bc");
     if (!read_file(bc_path, kernels_bc)) {
         log = "cannot read " + bc_path + " (run __graft_entry__.build())";
         return false;
     }
-    std::string source = std::string(kScenePrelude) + scene_cl + kSceneEpilogue + extra_cl;
+    std::string source = std::string(kScenePrelude) + scene_cl + kSceneEpilogue + extra_cl, source_key;
 
     // Extra compiler options for experiments (';'-separated), e.g. DCSG_JIT_EXTRA_OPTS="-mllvm;-vectorize-slp=false".
     // They take part in the cache key.
@@ -242,37 +292,54 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
         }
         for (auto& o : extra_opts) source += "\n// opt: " + o;
     }
-    uint64_t h1 = fnv1a64(source.data(), source.size(), 0xcbf29ce484222325ull);
+    // SLP vectorisation is off: on gfx950 the packed-f32 VALU ops it forms (v_pk_mul_f32 / v_pk_add_f32) issue
+    // slower than the scalar pairs they replace (measured: sphere sweep +15 %, Design2 +24 % with it off).
+    // Exact module: no contraction, IEEE divide/sqrt -- the numerics contract of kernels.hip.  "-w" as in the
+    // reference's build options (Utils.cpp:78-81).
+    std::vector<const char*> cl_opts, cg_opts;
+    if (relaxed) {
+        cl_opts = {"-DDCSG_RELAXED=1", "-ffp-contract=fast", "-cl-mad-enable", "-w", "-O3", "-fno-slp-vectorize"};
+        cg_opts = {"-O3", "-ffp-contract=fast", "-fno-slp-vectorize"};
+    } else {
+        cl_opts = {"-ffp-contract=off", "-cl-fp32-correctly-rounded-divide-sqrt", "-w", "-O3", "-fno-slp-vectorize"};
+        cg_opts = {"-O3", "-ffp-contract=off", "-fno-slp-vectorize"};
+    }
+    for (auto& o : extra_opts) {
+        cl_opts.push_back(o.c_str());
+        cg_opts.push_back(o.c_str());
+    }
+    // everything the code object depends on goes into the key: the text, the kernels' bitcode, the ISA, every
+    // compiler option, and the identity of the compiler (libamd_comgr's path and size stand in for its version)
+    {
+        std::string ident = std::string("\n// isa: ") + kIsa;
+        for (auto o : cl_opts) ident += std::string("\n// cl: ") + o;
+        for (auto o : cg_opts) ident += std::string("\n// cg: ") + o;
+        ident += "\n// comgr: " + comgr_identity();
+        source_key = source + ident;
+    }
+    uint64_t h1 = fnv1a64(source_key.data(), source_key.size(), 0xcbf29ce484222325ull);
     h1 = fnv1a64(kernels_bc.data(), kernels_bc.size(), h1);
-    uint64_t h2 = fnv1a64(source.data(), source.size(), 0x84222325cbf29ce4ull);
+    uint64_t h2 = fnv1a64(source_key.data(), source_key.size(), 0x84222325cbf29ce4ull);
     h2 = fnv1a64(kernels_bc.data(), kernels_bc.size(), h2);
     char key[40];
     snprintf(key, sizeof(key), "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
-    std::string cpath = cache_dir() + "/" + key + ".hsaco";
-    if (!getenv("DCSG_JIT_NO_CACHE") && read_file(cpath, hsaco) && hsaco.size() > 64) {
+    const std::string cdir = getenv("DCSG_JIT_NO_CACHE") ? std::string() : cache_dir();
+    const std::string cpath = cdir.empty() ? std::string() : cdir + "/" + key + ".hsaco";
+    if (!cpath.empty() && read_cached_code_object(cpath, hsaco)) {
         if (from_cache) *from_cache = true;
         return true;
     }
+    hsaco.clear();
 
     if (!comgr().handle || !comgr().error.empty()) {
         log = "cannot load the ROCm code object manager (libamd_comgr.so.3):\n" + comgr().error;
         return false;
     }
-    // 1. brush text (OpenCL C) -> gfx950 bitcode.  No contraction, IEEE divide/sqrt: the numerics
-    //    contract of kernels.hip.  "-w" as in the reference's build options (Utils.cpp:78-81).
+    // 1. brush text (OpenCL C) -> gfx950 bitcode
     ComgrSet src, bc;
     if (!src.ok || !bc.ok || !add_data(src.s, AMD_COMGR_DATA_KIND_SOURCE, "scene.cl", source)) {
         log = "comgr: cannot create source data";
         return false;
-    }
-    // SLP vectorisation is off: on gfx950 the packed-f32 VALU ops it forms (v_pk_mul_f32 / v_pk_add_f32) issue
-    // slower than the scalar pairs they replace (measured: sphere sweep +15 %, Design2 +24 % with it off).
-    std::vector<const char*> cl_opts = {"-ffp-contract=off", "-cl-fp32-correctly-rounded-divide-sqrt", "-w", "-O3",
-                                        "-fno-slp-vectorize"};
-    std::vector<const char*> cg_opts = {"-O3", "-ffp-contract=off", "-fno-slp-vectorize"};
-    for (auto& o : extra_opts) {
-        cl_opts.push_back(o.c_str());
-        cg_opts.push_back(o.c_str());
     }
     if (!run_action(AMD_COMGR_ACTION_COMPILE_SOURCE_WITH_DEVICE_LIBS_TO_BC, AMD_COMGR_LANGUAGE_OPENCL_2_0, cl_opts, src.s,
                     bc.s, log))
@@ -298,7 +365,7 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
         log += "comgr produced no executable\n";
         return false;
     }
-    write_file_atomic(cpath, hsaco);  // best effort
+    if (!cpath.empty()) write_file_atomic(cpath, hsaco);  // best effort
     return true;
 }
 

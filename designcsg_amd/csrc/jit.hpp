@@ -9,6 +9,8 @@ bool read_file(const std::string& path, std::string& out);
 // every kernel of kernels.hip linked against the scene's sdf_bank.  On failure log holds the
 // compiler diagnostics (what Evaluator::build returns as the build log, Evaluator.cpp:64-89).
 // extra_cl: generated OpenCL C appended after the epilogue (csrc/specialise.cpp).
+// relaxed: the opt-in relaxed-numerics module (kernels.hip built with DCSG_RELAXED: hardware sqrt / rsq, FMA
+// contraction, no IEEE division sequences) instead of the bit-exact one.
 bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, std::string& hsaco, std::string& log,
-                      bool* from_cache);
+                      bool* from_cache, bool relaxed = false);
 }  // namespace dcsg

@@ -50,6 +50,12 @@
 // point in the fused sweep); any other wave (tiny, zero, negative, NaN) takes the compiler's full sequence.
 // tests/test_gpu_parity.py::test_sqrt_all_float_inputs checks all 2^32 bit patterns against IEEE sqrtf.
 // ---------------------------------------------------------------------------
+#ifdef DCSG_RELAXED
+// Opt-in relaxed numerics (dcsg_set_numerics(ctx, DCSG_NUMERICS_RELAXED); built as a separate bitcode with FMA
+// contraction allowed): the hardware square root (1 ulp), normalize through v_rsq_f32, no double-precision scale of
+// the gradient.  Results are NOT bit-identical to the reference arithmetic; tests hold them to 1e-5.
+__device__ __forceinline__ float dcsg_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
 __device__ __forceinline__ float dcsg_sqrt(float x)
 {
     float r = __builtin_amdgcn_sqrtf(x);
@@ -63,6 +69,7 @@ __device__ __forceinline__ float dcsg_sqrt(float x)
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f)) != 0ull, 0)) r = __builtin_sqrtf(x);
     return r;
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // wave / block reductions and scans
@@ -120,9 +127,6 @@ __device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_
 // stencil point -- for 7 points (elements 0..6 of the float8s) and for 1 point.  Same arithmetic in the same
 // order as the interpreters, so the results are bit-identical; no decode, no tables, no LDS.
 typedef float dcsg_cl_float8 __attribute__((ext_vector_type(8)));
-typedef float dcsg_cl_float16 __attribute__((ext_vector_type(16)));
-// 14 = the 7-point stencils of two lattice points that differ only in z (elements 0..6 and 7..13)
-extern "C" __device__ dcsg_cl_float16 dcsg_spec_eval14(dcsg_cl_float16 px, dcsg_cl_float16 py, dcsg_cl_float16 pz);
 extern "C" __device__ dcsg_cl_float8 dcsg_spec_eval7(dcsg_cl_float8 px, dcsg_cl_float8 py, dcsg_cl_float8 pz);
 extern "C" __device__ float dcsg_spec_eval1(float x, float y, float z);
 // dcsg_spec_eval1 with every term of every transform written out: valid for any input (the three above may
@@ -329,6 +333,21 @@ __device__ __forceinline__ float dcsg_div_by(float n, float d, float r1)
     return __builtin_fmaf(e3, r1, q1);
 }
 
+#ifdef DCSG_RELAXED
+__device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
+{
+    float q = x * x + y * y + z * z;
+    float r = q > 0.0f ? __builtin_amdgcn_rsqf(q) : 0.0f;  // zero vector stays zero
+    x *= r;
+    y *= r;
+    z *= r;
+}
+__device__ __forceinline__ void dcsg_finish_normal(float Dx, float Dy, float Dz, float& nx, float& ny, float& nz)
+{
+    nx = Dx, ny = Dy, nz = Dz;  // the scale 1/(2 eps) cancels in the normalisation
+    dcsg_normalize(nx, ny, nz);
+}
+#else
 // OpenCL normalize(float3) pinned as v / length(v), zero vector stays zero.
 __device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
 {
@@ -364,6 +383,7 @@ __device__ __forceinline__ void dcsg_finish_normal(float Dx, float Dy, float Dz,
     nz = (float)(k * (double)Dz);
     dcsg_normalize(nx, ny, nz);
 }
+#endif
 
 // get_normal, k2.cl:149-179
 __device__ __forceinline__ void dcsg_get_normal(const SceneLds& s, float x, float y, float z, float& nx, float& ny,
@@ -892,66 +912,174 @@ __device__ __forceinline__ unsigned int dcsg_div_n1(const DcsgLattice& L, unsign
 }
 
 // ---------------------------------------------------------------------------
-// Kernel 1: fused lattice sweep.  One thread per lattice point, x fastest, so a wave stores
-// 256 contiguous bytes of SDF and 768 contiguous bytes of normals.  `first` is the flat index of
-// this launch's first point inside the slab buffer, plane z0 is the slab's first plane.
-// Algorithmic traffic: 16 B written per point, nothing read (positions come from the index, the
-// op and object tables from LDS).
-// K = stack depth of the register-resident stack interpreter; K = 0 instantiates the generic
-// LDS-stack interpreter (programs that are not stack-disciplined, or deeper than 8).
+// Wave-level lattice indexing for the dense sweeps.
+//
+// A wave's 64 points are consecutive in the flat index, so (ix,iy,iz) of the wave's FIRST point is wave-uniform:
+// it is decomposed once per wave on the scalar unit (s_mul_hi_u32 magic divisions, no VALU work), and a lane's
+// point is (ix0 + lane, iy0, iz0) -- or, past the end of the row, the next row (rows hold res+1 >= 64 points, so a
+// wave crosses at most one row end).  The three coordinates come from per-axis tables of ISV3D64::getPoint
+// (ISV.hpp:103-109) that each block computes once into LDS with exactly the arithmetic of dcsg_lattice_coord:
+// same bits, and the per-point cost of index -> position drops from ~30 VALU instructions (two per-lane magic
+// divisions, three int -> float conversions, six multiplies / adds) to one add plus the LDS reads.
+// Lattices with fewer than 64 points per row, or too large for the tables to fit in LDS (axes_off < 0), take the
+// per-lane path.
 // ---------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, int n_vec4, const DcsgLattice& L, int z0,
-                                                unsigned int first, unsigned int n_points,
-                                                float* __restrict__ sdf_out, float* __restrict__ nrm_out)
+__device__ __forceinline__ const float* dcsg_stage_axes(const DcsgLattice& L, int axes_off)
 {
-    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    if (axes_off < 0 || L.res + 1 < DCSG_WAVE) return nullptr;
+    float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(dcsg_lds) + axes_off);
+    const int n1 = L.res + 1;
+    for (int k = 0; k < 3; k++)
+        for (int i = threadIdx.x; i < n1; i += DCSG_BLOCK) tab[k * n1 + i] = dcsg_lattice_coord(L, k, i);
+    __syncthreads();
+    return tab;
+}
+
+// Position of this lane's point when the wave's first point is (ix0, iy0) of lattice plane plane0 (all wave-uniform).
+// `ax` = the LDS tables.  wrapped: the lane sits in the next row.
+struct DcsgWavePoint {
+    float x, y, z;
+    bool wrapped;  // lane is past the end of the wave's first row
+};
+__device__ __forceinline__ DcsgWavePoint dcsg_wave_point(const DcsgLattice& L, const float* ax, unsigned int ix0, unsigned int iy0,
+                                                         unsigned int plane0, unsigned int lane)
+{
     const unsigned int n1 = (unsigned int)L.res + 1u;
-    const unsigned int tiles = (n_points + DCSG_BLOCK - 1) / DCSG_BLOCK;
-    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        unsigned int local = tile * DCSG_BLOCK + threadIdx.x;
-        if (local >= n_points) continue;
-        unsigned int idx = first + local;
-        unsigned int t = dcsg_div_n1(L, idx);
-        unsigned int ix = idx - t * n1;
-        unsigned int iz = dcsg_div_n1(L, t);
-        unsigned int iy = t - iz * n1;
-        float x = dcsg_lattice_coord(L, 0, (int)ix);
-        float y = dcsg_lattice_coord(L, 1, (int)iy);
-        float z = dcsg_lattice_coord(L, 2, (int)iz + z0);
-        float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
-        if (K == 0) {
-            if (sdf_out) sd = dcsg_primary_sdf(s, x, y, z);
-            if (nrm_out) dcsg_get_normal(s, x, y, z, nx, ny, nz);
-#ifdef DCSG_HAVE_SPEC
-        } else if (K < 0) {
-            dcsg_stencil_spec<true>(x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
-#endif
-        } else {
-            dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
+    DcsgWavePoint w;
+    if (ix0 + (DCSG_WAVE - 1u) < n1) {  // wave-uniform: the whole wave lies in one row
+        w.x = ax[ix0 + lane];
+        w.y = ax[n1 + iy0];
+        w.z = ax[2u * n1 + plane0];
+        w.wrapped = false;
+    } else {
+        unsigned int iy1 = iy0 + 1u, plane1 = plane0;
+        if (iy1 == n1) {
+            iy1 = 0u;
+            plane1 = plane0 + 1u;
         }
-        if (sdf_out) sdf_out[idx] = sd;
-        if (nrm_out) {
-            float* o = nrm_out + (size_t)idx * 3;
-            o[0] = nx;
-            o[1] = ny;
-            o[2] = nz;
+        // plane1 can be res + 1 only for lanes past the end of the lattice, which store nothing: keep the read in range
+        const unsigned int plane1c = plane1 > (unsigned int)L.res ? (unsigned int)L.res : plane1;
+        unsigned int ix = ix0 + lane;
+        w.wrapped = ix >= n1;
+        ix = w.wrapped ? ix - n1 : ix;
+        w.x = ax[ix];
+        w.y = ax[n1 + (w.wrapped ? iy1 : iy0)];
+        w.z = ax[2u * n1 + (w.wrapped ? plane1c : plane0)];
+    }
+    return w;
+}
+// (ix0, iy0, plane0) of the point 64 flat indices further on (scalar unit; rows hold >= 64 points)
+__device__ __forceinline__ void dcsg_wave_advance(unsigned int n1, unsigned int& ix0, unsigned int& iy0, unsigned int& plane0)
+{
+    ix0 += DCSG_WAVE;
+    if (ix0 >= n1) {
+        ix0 -= n1;
+        iy0 += 1u;
+        if (iy0 == n1) {
+            iy0 = 0u;
+            plane0 += 1u;
         }
     }
 }
 
-#define DCSG_SWEEP_KERNEL(NAME, K)                                                                                  \
+// ---------------------------------------------------------------------------
+// Kernel 1: fused lattice sweep.  One thread per lattice point, x fastest, so a wave stores
+// 256 contiguous bytes of SDF and 768 contiguous bytes of normals per pass; a wave owns a run of
+// DCSG_RUN = 4 x 64 consecutive points (one scalar index decomposition per run, then scalar increments).
+// `first` is the flat index of this launch's first point inside the slab buffer, plane z0 is the slab's first plane.
+// Algorithmic traffic: 16 B written per point, nothing read (positions come from the index, the
+// op and object tables from LDS).
+// K = stack depth of the register-resident stack interpreter; K = 0 instantiates the generic
+// LDS-stack interpreter (programs that are not stack-disciplined, or deeper than 8); K < 0 the per-scene
+// specialised code.  MODE fixes the outputs at compile time (1: SDF only, 3: SDF + normals; no mode tests or dead
+// paths in the loop); MODE 0 reads them off the pointers at run time (normals only, and the kernels kept small).
+// ---------------------------------------------------------------------------
+#define DCSG_RUN (4u * DCSG_WAVE)
+template <int K, int MODE>
+__device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, int n_vec4, const DcsgLattice& L, int z0,
+                                                unsigned int first, unsigned int n_points,
+                                                float* __restrict__ sdf_out, float* __restrict__ nrm_out, int axes_off)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    const float* ax = dcsg_stage_axes(L, axes_off);
+    const bool want_sdf = MODE == 0 ? sdf_out != nullptr : true;
+    const bool want_nrm = MODE == 0 ? nrm_out != nullptr : MODE == 3;
+    const unsigned int n1 = (unsigned int)L.res + 1u;
+    const unsigned int tile_points = DCSG_RUN * (DCSG_BLOCK / DCSG_WAVE);
+    const unsigned int tiles = (n_points + tile_points - 1u) / tile_points;
+    const unsigned int lane = threadIdx.x & (DCSG_WAVE - 1u);
+    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / DCSG_WAVE));
+    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const unsigned int local0 = tile * tile_points + wave * DCSG_RUN;  // wave-uniform from here ...
+        if (local0 >= n_points) continue;
+        const unsigned int left = n_points - local0;
+        unsigned int idx0 = first + local0;
+        unsigned int ix0 = 0u, iy0 = 0u, plane0 = 0u;
+        if (ax) {
+            const unsigned int t0 = dcsg_div_n1(L, idx0);
+            ix0 = idx0 - t0 * n1;
+            const unsigned int iz0 = dcsg_div_n1(L, t0);
+            iy0 = t0 - iz0 * n1;
+            plane0 = iz0 + (unsigned int)z0;                                // ... to here
+        }
+#pragma unroll 1
+        for (unsigned int done = 0u; done < DCSG_RUN && done < left; done += DCSG_WAVE, idx0 += DCSG_WAVE) {
+            float x, y, z;
+            if (ax) {
+                DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
+                x = w.x, y = w.y, z = w.z;
+                dcsg_wave_advance(n1, ix0, iy0, plane0);
+            } else {
+                unsigned int idx = idx0 + lane;
+                unsigned int t = dcsg_div_n1(L, idx);
+                unsigned int ix = idx - t * n1;
+                unsigned int iz = dcsg_div_n1(L, t);
+                unsigned int iy = t - iz * n1;
+                x = dcsg_lattice_coord(L, 0, (int)ix);
+                y = dcsg_lattice_coord(L, 1, (int)iy);
+                z = dcsg_lattice_coord(L, 2, (int)iz + z0);
+            }
+            if (left - done < DCSG_WAVE && lane >= left - done) continue;  // the launch's last wave
+            float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+            if (K == 0) {
+                if (want_sdf) sd = dcsg_primary_sdf(s, x, y, z);
+                if (want_nrm) dcsg_get_normal(s, x, y, z, nx, ny, nz);
+#ifdef DCSG_HAVE_SPEC
+            } else if (K < 0) {
+                dcsg_stencil_spec<true>(x, y, z, want_sdf, want_nrm, sd, nx, ny, nz);
+#endif
+            } else {
+                dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, want_sdf, want_nrm, sd, nx, ny, nz);
+            }
+            // wave-uniform base + lane: the store addresses cost no per-lane multiplies
+            if (want_sdf) (sdf_out + idx0)[lane] = sd;
+            if (want_nrm) {
+                float* o = nrm_out + (size_t)idx0 * 3 + lane * 3u;
+                o[0] = nx;
+                o[1] = ny;
+                o[2] = nz;
+            }
+        }
+    }
+}
+
+#define DCSG_SWEEP_KERNEL(NAME, K, MODE)                                                                            \
     extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                        \
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,                     \
-         unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out)                           \
+         unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out, int axes_off)             \
     {                                                                                                               \
-        dcsg_sweep_body<K>(blob, n_vec4, L, z0, first, n_points, sdf_out, nrm_out);                                 \
+        dcsg_sweep_body<K, MODE>(blob, n_vec4, L, z0, first, n_points, sdf_out, nrm_out, axes_off);                 \
     }
-DCSG_SWEEP_KERNEL(dcsg_sweep, 0)
-DCSG_SWEEP_KERNEL(dcsg_sweep_s4, 4)
-DCSG_SWEEP_KERNEL(dcsg_sweep_s8, 8)
+// NAME: outputs chosen at run time; NAME_d: SDF only; NAME_f: SDF + normals
+#define DCSG_SWEEP_KERNELS(NAME, K)                                                                                 \
+    DCSG_SWEEP_KERNEL(NAME, K, 0)                                                                                   \
+    DCSG_SWEEP_KERNEL(NAME##_d, K, 1)                                                                               \
+    DCSG_SWEEP_KERNEL(NAME##_f, K, 3)
+DCSG_SWEEP_KERNELS(dcsg_sweep, 0)
+DCSG_SWEEP_KERNELS(dcsg_sweep_s4, 4)
+DCSG_SWEEP_KERNELS(dcsg_sweep_s8, 8)
 #ifdef DCSG_HAVE_SPEC
-DCSG_SWEEP_KERNEL(dcsg_sweep_sp, -1)
+DCSG_SWEEP_KERNELS(dcsg_sweep_sp, -1)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -984,6 +1112,40 @@ __device__ __forceinline__ bool dcsg_node_culled(float d, float hx, float hy, fl
     return __builtin_fabsf(d) > mag * 1.1f;
 }
 
+// Local point index p of a node block -> (lx, ly, lz), p = (lz*side + ly)*side + lx, without integer division:
+// side = 2^shift + 1 <= 33 and p < side^3 < 2^16, for which floor(p * (floor(2^32/d) + 1) / 2^32) = p / d exactly.
+struct DcsgNodeGrid {
+    unsigned int side, ss, pts, m_side, m_ss;
+};
+__device__ __forceinline__ DcsgNodeGrid dcsg_node_grid(int shift)
+{
+    DcsgNodeGrid g;
+    g.side = (1u << shift) + 1u;
+    g.ss = g.side * g.side;
+    g.pts = g.ss * g.side;
+    g.m_side = 0xffffffffu / g.side + 1u;
+    g.m_ss = 0xffffffffu / g.ss + 1u;
+    return g;
+}
+__device__ __forceinline__ void dcsg_node_local(const DcsgNodeGrid& g, unsigned int p, unsigned int& lx, unsigned int& ly, unsigned int& lz)
+{
+    lz = __umulhi(p, g.m_ss);
+    unsigned int r = p - lz * g.ss;
+    ly = __umulhi(r, g.m_side);
+    lx = r - ly * g.side;
+}
+// The node's 3 x side lattice coordinates (ISV.hpp:103-109) once per node into LDS; tab[k*40 + j] = axis k, index i0[k]+j.
+#define DCSG_NODE_TAB 40
+__device__ __forceinline__ void dcsg_node_axes(const DcsgLattice& L, const int (&i0)[3], unsigned int side, float* tab)
+{
+    __syncthreads();  // the previous node's readers are done
+    if (threadIdx.x < 3u * DCSG_NODE_TAB) {
+        const unsigned int k = threadIdx.x / DCSG_NODE_TAB, j = threadIdx.x - k * DCSG_NODE_TAB;
+        if (j < side) tab[threadIdx.x] = dcsg_lattice_coord(L, (int)k, i0[k] + (int)j);
+    }
+    __syncthreads();
+}
+
 template <int K>
 __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ blob, int n_vec4, const DcsgLattice& L,
                                                       const float* __restrict__ nodes, unsigned int n_nodes, int shift, int level,
@@ -991,7 +1153,9 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
                                                       unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
-    const unsigned int n1 = (unsigned int)L.res + 1u, side = (1u << shift) + 1u, pts = side * side * side;
+    __shared__ float tab[3 * DCSG_NODE_TAB];
+    const DcsgNodeGrid g = dcsg_node_grid(shift);
+    const size_t n1 = (size_t)L.res + 1u;
     for (unsigned int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
         int i0[3], ic[3];
         size_t slot;
@@ -1007,10 +1171,12 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
             if (dcsg_node_culled(d, hdx, hdy, hdz)) continue;
         }
         if (threadIdx.x == 0) node_mask[slot] = 1;
-        for (unsigned int p = threadIdx.x; p < pts; p += DCSG_BLOCK) {
-            unsigned int lz = p / (side * side), r = p - lz * side * side, ly = r / side, lx = r - ly * side;
-            unsigned int ix = (unsigned int)i0[0] + lx, iy = (unsigned int)i0[1] + ly, iz = (unsigned int)i0[2] + lz;
-            float x = dcsg_lattice_coord(L, 0, (int)ix), y = dcsg_lattice_coord(L, 1, (int)iy), z = dcsg_lattice_coord(L, 2, (int)iz);
+        dcsg_node_axes(L, i0, g.side, tab);
+        const size_t base = ((size_t)i0[2] * n1 + (size_t)i0[1]) * n1 + (size_t)i0[0];
+        for (unsigned int p = threadIdx.x; p < g.pts; p += DCSG_BLOCK) {
+            unsigned int lx, ly, lz;
+            dcsg_node_local(g, p, lx, ly, lz);
+            float x = tab[lx], y = tab[DCSG_NODE_TAB + ly], z = tab[2 * DCSG_NODE_TAB + lz];
             float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
             if (K == 0) {
                 if (sdf_out) sd = dcsg_primary_sdf(s, x, y, z);
@@ -1022,7 +1188,7 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
             } else {
                 dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
             }
-            size_t idx = ((size_t)iz * n1 + iy) * n1 + ix;
+            size_t idx = base + ((size_t)lz * n1 + ly) * n1 + lx;
             if (sdf_out) sdf_out[idx] = sd;
             if (nrm_out) {
                 float* o = nrm_out + idx * 3;
@@ -1049,74 +1215,6 @@ DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_s8, 8)
 #ifdef DCSG_HAVE_SPEC
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_sp, -1)
 
-// Specialised fused sweep, two lattice planes per thread: point (ix,iy,iz) and (ix,iy,iz+1) are evaluated
-// in one call (14 stencil points).  The object transform is A = (dx*rx + dy*ry) + dz*rz (k2.cl:111,
-// left to right), so for two points that differ only in z everything but the last term is the same
-// expression on the same values: value numbering computes it once.  Same arithmetic, same bits; ~45 % of
-// the transform work and half of the index math disappear.  The launch covers whole planes
-// (n_points = planes * (res+1)^2, first = multiple of (res+1)^2); an odd last plane is evaluated alone.
-extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
-dcsg_sweep_sp2(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,
-               unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out)
-{
-    const unsigned int n1 = (unsigned int)L.res + 1u;
-    const unsigned int plane = n1 * n1;
-    const unsigned int planes = dcsg_div_n1(L, dcsg_div_n1(L, n_points));
-    const unsigned int first_plane = dcsg_div_n1(L, dcsg_div_n1(L, first));
-    const unsigned int pairs = (planes + 1u) >> 1;
-    const unsigned int items = pairs * plane;
-    const unsigned int tiles = (items + DCSG_BLOCK - 1) / DCSG_BLOCK;
-    const float e = (float)K2_NORMAL_EPSILON;
-    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        unsigned int item = tile * DCSG_BLOCK + threadIdx.x;
-        if (item >= items) continue;
-        // item = pair * plane + (iy * n1 + ix)
-        unsigned int t = dcsg_div_n1(L, item);
-        unsigned int ix = item - t * n1;
-        unsigned int pr = dcsg_div_n1(L, t);
-        unsigned int iy = t - pr * n1;
-        unsigned int izl = 2u * pr;                      // plane index inside this launch
-        bool second = izl + 1u < planes;
-        unsigned int idx0 = first + izl * plane + iy * n1 + ix;
-        float x = dcsg_lattice_coord(L, 0, (int)ix);
-        float y = dcsg_lattice_coord(L, 1, (int)iy);
-        float za = dcsg_lattice_coord(L, 2, (int)(first_plane + izl) + z0);
-        float zb = dcsg_lattice_coord(L, 2, (int)(first_plane + izl + 1u) + z0);
-        float sd[2] = {0.0f, 0.0f}, n[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-        bool nzero = dcsg_is_neg_zero(x) || dcsg_is_neg_zero(y) || dcsg_is_neg_zero(za) || dcsg_is_neg_zero(zb);
-        if (!nrm_out || __builtin_amdgcn_ballot_w64(nzero) != 0ull) {
-            // SDF-only sweeps and waves with a -0.0 coordinate: the one-point paths
-            dcsg_stencil_spec<true>(x, y, za, sdf_out != nullptr, nrm_out != nullptr, sd[0], n[0][0], n[0][1], n[0][2]);
-            if (second) dcsg_stencil_spec<true>(x, y, zb, sdf_out != nullptr, nrm_out != nullptr, sd[1], n[1][0], n[1][1], n[1][2]);
-        } else {
-            float xp = x + e, xm = x - e, yp = y + e, ym = y - e;
-            dcsg_cl_float16 px = {x, xp, xm, x, x, x, x, x, xp, xm, x, x, x, x, 0.0f, 0.0f};
-            dcsg_cl_float16 py = {y, y, y, yp, ym, y, y, y, y, y, yp, ym, y, y, 0.0f, 0.0f};
-            dcsg_cl_float16 pz = {za, za, za, za, za, za + e, za - e, zb, zb, zb, zb, zb, zb + e, zb - e, 0.0f, 0.0f};
-            dcsg_cl_float16 o = dcsg_spec_eval14(px, py, pz);
-            sd[0] = o[0];
-            sd[1] = o[7];
-            dcsg_finish_normal(o[1] - o[2], o[3] - o[4], o[5] - o[6], n[0][0], n[0][1], n[0][2]);
-            dcsg_finish_normal(o[8] - o[9], o[10] - o[11], o[12] - o[13], n[1][0], n[1][1], n[1][2]);
-        }
-        if (sdf_out) {
-            sdf_out[idx0] = sd[0];
-            if (second) sdf_out[idx0 + plane] = sd[1];
-        }
-        if (nrm_out) {
-            float* o0 = nrm_out + (size_t)idx0 * 3;
-            o0[0] = n[0][0];
-            o0[1] = n[0][1];
-            o0[2] = n[0][2];
-            if (second) {
-                float* o1 = nrm_out + ((size_t)idx0 + plane) * 3;
-                o1[0] = n[1][0];
-                o1[1] = n[1][1];
-                o1[2] = n[1][2];
-            }
-        }
-    }
-}
 #endif
 
 // ---------------------------------------------------------------------------
@@ -1754,7 +1852,7 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
 // is hundreds of object evaluations per point, where store shape is irrelevant next to the work removed.
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_sweep_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,
-              unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out)
+              unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out, int /*axes_off: unused*/)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     const unsigned int n1 = (unsigned int)L.res + 1u;
@@ -1845,7 +1943,10 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
                     unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
-    const unsigned int n1 = (unsigned int)L.res + 1u, side = (1u << shift) + 1u, pts = side * side * side;
+    __shared__ float tab[3 * DCSG_NODE_TAB];
+    const DcsgNodeGrid g = dcsg_node_grid(shift);
+    const unsigned int side = g.side, pts = g.pts;
+    const size_t n1 = (size_t)L.res + 1u;
     const float pad = nrm_out ? (float)K2_NORMAL_EPSILON * 1.01f : 0.0f;
     for (unsigned int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
         int i0[3], ic[3];
@@ -1868,17 +1969,19 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
             if (dcsg_node_culled(d, hdx, hdy, hdz)) continue;
         }
         if (threadIdx.x == 0) node_mask[slot] = 1;
+        dcsg_node_axes(L, i0, side, tab);
+        const size_t base = ((size_t)i0[2] * n1 + (size_t)i0[1]) * n1 + (size_t)i0[0];
         for (unsigned int p0 = 0; p0 < pts; p0 += DCSG_BLOCK) {
             unsigned int p = p0 + threadIdx.x;
             bool valid = p < pts;
             unsigned int cp = valid ? p : pts - 1u;  // idle lanes evaluate the last point and store nothing
-            unsigned int lz = cp / (side * side), r = cp - lz * side * side, ly = r / side, lx = r - ly * side;
-            unsigned int ix = (unsigned int)i0[0] + lx, iy = (unsigned int)i0[1] + ly, iz = (unsigned int)i0[2] + lz;
-            float x = dcsg_lattice_coord(L, 0, (int)ix), y = dcsg_lattice_coord(L, 1, (int)iy), z = dcsg_lattice_coord(L, 2, (int)iz);
+            unsigned int lx, ly, lz;
+            dcsg_node_local(g, cp, lx, ly, lz);
+            float x = tab[lx], y = tab[DCSG_NODE_TAB + ly], z = tab[2 * DCSG_NODE_TAB + lz];
             float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
             dcsg_stencil<4>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz, list, n_list);
             if (valid) {
-                size_t idx = ((size_t)iz * n1 + iy) * n1 + ix;
+                size_t idx = base + ((size_t)lz * n1 + ly) * n1 + lx;
                 if (sdf_out) sdf_out[idx] = sd;
                 if (nrm_out) {
                     float* o = nrm_out + idx * 3;

@@ -76,6 +76,17 @@ bool parse_scene(const char* scene_txt, const char* bp_txt, Scene& s, std::strin
         s.n_steps++;
         p = skip_ws(p);
     }
+    // k2.cl's switch ignores opcodes it does not know (k2.cl:59-140): such steps are dropped HERE, before anything
+    // looks at their operands.  The numbers 16.. and 32.. are the host's own fused / stack opcodes (optimise_program)
+    // and must never be taken from a file.
+    {
+        std::vector<int32_t> kept;
+        kept.reserve(s.steps.size());
+        for (int c = 0; c < s.n_steps; c++)
+            if (s.steps[4 * c] >= 0 && s.steps[4 * c] <= 8) kept.insert(kept.end(), s.steps.begin() + 4 * c, s.steps.begin() + 4 * c + 4);
+        s.steps.swap(kept);
+        s.n_steps = (int)(s.steps.size() / 4);
+    }
     // Validation: everything the kernels index with must be in range.
     int max_slot = -1;
     auto slot_ok = [&](int a, const char* what, int step) {
@@ -131,13 +142,18 @@ bool parse_scene(const char* scene_txt, const char* bp_txt, Scene& s, std::strin
             }
             have_k = true;
         } break;
-        default:  // k2.cl's switch ignores unknown opcodes; so do the kernels
-            break;
+        default:  // unreachable: unknown opcodes were dropped above
+            err = "internal: unknown opcode survived the filter";
+            return false;
         }
     }
     s.n_slots = max_slot + 1;
     if (s.n_slots < 1) s.n_slots = 1;
     optimise_program(s);
+    if (s.invalid_program) {
+        err = "buildprocedure.txt: a step addresses a slot outside 0.." + std::to_string(DCSG_MAX_SLOTS - 1);
+        return false;
+    }
     return true;
 }
 
@@ -376,6 +392,18 @@ void optimise_program(Scene& s)
     }
     // ---- liveness renaming ---------------------------------------------------------------------
     const int NV = DCSG_MAX_SLOTS;
+    for (const Step& t : out) {  // parse_scene validated every slot; a violation here is a host bug, not bad input
+        int rd[2], wr;
+        step_access(t, rd, wr);
+        for (int v : {rd[0], rd[1], wr})
+            if (v < -1 || v >= NV) {  // leave no program behind: the caller reports the scene as invalid
+                s.prog.clear();
+                s.stack_prog.clear();
+                s.n_prog = s.n_stack_prog = 0;
+                s.invalid_program = true;
+                return;
+            }
+    }
     int first[NV], last[NV];
     bool read_first[NV];
     for (int v = 0; v < NV; v++) first[v] = last[v] = -2, read_first[v] = false;

@@ -17,6 +17,7 @@ struct Scene {
     std::vector<uint8_t> material;             // [n_objects] second column of scene.txt (preview only)
     std::vector<float> pos, right, up, fwd;    // [3*n_objects]
     std::vector<int32_t> steps;                // [4*n_steps] opcode,left,right,dest  (as in buildprocedure.txt)
+    bool invalid_program = false;              // optimise_program met a slot outside 0..DCSG_MAX_SLOTS-1 (cannot happen after parse_scene)
     std::vector<int32_t> prog;                 // internal program: fused + slots renamed (optimise_program)
     int n_prog = 0;                            // steps in prog
     int n_regs = 0;                            // stack registers prog needs (<= n_slots)

@@ -28,6 +28,10 @@ float3 shader_bank(float3 gv, float3 lv, float3 n, unsigned char material_id);
 #define DCSG_OVL __attribute__((overloadable))
 /* Correctly rounded sqrtf: same sequence as dcsg_sqrt in kernels.hip (fast path for waves whose inputs are
  * all >= 2^-96, the compiler's full IEEE expansion otherwise). */
+#ifdef DCSG_RELAXED
+/* opt-in relaxed numerics (dcsg_set_numerics): the hardware square root, 1 ulp */
+float dcsg_sqrt_ieee(float x){ return __builtin_amdgcn_sqrtf(x); }
+#else
 float dcsg_sqrt_ieee(float x){
     float r = __builtin_amdgcn_sqrtf(x);
     float rm = as_float(as_uint(r) - 1u);
@@ -39,6 +43,7 @@ float dcsg_sqrt_ieee(float x){
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f)) != 0ul, 0)) r = __builtin_sqrtf(x);
     return r;
 }
+#endif
 float  DCSG_OVL sqrt(float x){ return dcsg_sqrt_ieee(x); }
 double DCSG_OVL sqrt(double x){ return __builtin_sqrt(x); }
 float  DCSG_OVL fabs(float x){ return __builtin_fabsf(x); }

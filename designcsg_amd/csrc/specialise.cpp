@@ -34,12 +34,14 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
         out += line;
     };
     static const char* hexdigit = "0123456789abcdef";
-    if (N == 14)
-        out += "float16 dcsg_spec_eval14(float16 px, float16 py, float16 pz){\n";
-    else if (N == 7)
-        out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){\n";
+    // always_inline: whether the evaluation is inlined into a kernel must not depend on how many kernels of the module
+    // call it (the stencil points share sub-expressions with their caller only when it is)
+    const bool exact_copy = std::string(name1) == "dcsg_spec_eval1x";  // rare path, kept out of line by its caller
+    const char* inl = exact_copy ? "" : "__attribute__((always_inline)) ";
+    if (N == 7)
+        out += std::string(inl) + "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){\n";
     else
-        out += std::string("float ") + name1 + "(float x, float y, float z){\n";
+        out += std::string(inl) + "float " + name1 + "(float x, float y, float z){\n";
     auto X = [&](int k) { return N > 1 ? std::string("px.s") + hexdigit[k] : std::string("x"); };
     auto Y = [&](int k) { return N > 1 ? std::string("py.s") + hexdigit[k] : std::string("y"); };
     auto Z = [&](int k) { return N > 1 ? std::string("pz.s") + hexdigit[k] : std::string("z"); };
@@ -67,6 +69,7 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
         auto S = [&](int d, int k) { return "s" + std::to_string(d) + "_" + std::to_string(k); };
         if ((op >= PUSH && op <= ACC_NEGMAX) || (op >= ACC_SMIN && op <= ACC_NEGSMAX)) {
             int t = tmp++;
+            bool obj_simplified = brush == 0 && null_brush_const;  // set below when the object's transform was simplified
             out += "  {\n";
             if (brush == 0 && null_brush_const) {
                 for (int k = 0; k < N; k++) P("    const float r%d = (float)MAX_DISTANCE;\n", k);
@@ -83,9 +86,14 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
                 // left out, "* 1.0f" and "- 0.0f" are dropped.  For finite coordinates (|v| <= 1e30, guaranteed by the
                 // callers; anything else takes dcsg_spec_eval1x) such a product is +-0 and adding it changes nothing but,
                 // possibly, the sign of a zero sum -- which no standard brush can see (squares, fabs).  Same bits out.
-                auto finite_small = [](float v) { return v - v == 0.0f && v <= 1e30f && v >= -1e30f; };
+                // The argument needs every product and three-term sum to stay finite (an overflow to +-inf would turn
+                // "+ 0 * dx" into NaN in the full form and into nothing in the short one): coordinates are <= 1e30 in
+                // magnitude, so coefficients and origins are held to 1e3 -- max |term| <= 1e3 * (1e30 + 1e3) and a sum of
+                // three stays below FLT_MAX.  Objects beyond that keep the written-out form.
+                auto finite_small = [](float v) { return v - v == 0.0f && v <= 1e3f && v >= -1e3f; };
                 bool simp = simplify;
                 for (int q = 0; q < 3; q++) simp = simp && finite_small(o[q]) && finite_small(r[q]) && finite_small(u[q]) && finite_small(f[q]);
+                obj_simplified = simp;
                 auto row = [&](int k, const float* c, const char* cn) {
                     std::string e;
                     const char* d[3] = {"dx", "dy", "dz"};
@@ -116,7 +124,7 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
             // `simplify` scenes: right after "PUSH null brush" the accumulator is the constant MAX_DISTANCE and the value
             // joined to it cannot be NaN (standard brushes, finite coordinates), so T_min(64, r) = (64 < r ? 64 : r) is
             // the IEEE minimum: one v_min_f32 instead of compare + select.  Same value for every non-NaN r.
-            const bool acc_is_max_distance = simplify && op == ACC_MIN && c > 0 && s.stack_prog[4 * (c - 1)] == PUSH &&
+            const bool acc_is_max_distance = simplify && obj_simplified && op == ACC_MIN && c > 0 && s.stack_prog[4 * (c - 1)] == PUSH &&
                                              (s.stack_prog[4 * (c - 1) + 1] & 0xff) == 0 && null_brush_const &&
                                              s.stack_prog[4 * (c - 1) + 3] == depth - 1;
             for (int k = 0; k < N; k++) {
@@ -145,9 +153,7 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
             for (int k = 0; k < N; k++) P("  o%d = s%d_%d;\n", k, depth - 1, k);
         }
     }
-    if (N == 14)
-        out += "  return (float16)(o0, o1, o2, o3, o4, o5, o6, o7, o8, o9, o10, o11, o12, o13, 0.0f, 0.0f);\n}\n";
-    else if (N == 7)
+    if (N == 7)
         out += "  return (float8)(o0, o1, o2, o3, o4, o5, o6, 0.0f);\n}\n";
     else
         out += "  return o0;\n}\n";
@@ -160,13 +166,11 @@ std::string specialised_source(const Scene& s, bool null_brush_const, bool enabl
 {
     std::string out = "\n/* ---- generated by csrc/specialise.cpp ---- */\n";
     if (!enable || s.n_stack_prog == 0) {
-        out += "float16 dcsg_spec_eval14(float16 px, float16 py, float16 pz){ return (float16)(0.0f); }\n";
         out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){ return (float8)(0.0f); }\n";
         out += "float dcsg_spec_eval1(float x, float y, float z){ return 0.0f; }\n";
         out += "float dcsg_spec_eval1x(float x, float y, float z){ return 0.0f; }\n";
         return out;
     }
-    emit_function(s, null_brush_const, 14, simplify, "", out);
     emit_function(s, null_brush_const, 7, simplify, "", out);
     emit_function(s, null_brush_const, 1, simplify, "dcsg_spec_eval1", out);
     emit_function(s, null_brush_const, 1, false, "dcsg_spec_eval1x", out);  // every term written out: any input

@@ -58,6 +58,11 @@ class Evaluator:
     def _ck(self, rc):
         return _lib.check(self._h, rc)
 
+    def set_numerics(self, mode):
+        """Arithmetic of the scenes built after this call: "exact" (default; bit-identical to the reference arithmetic)
+        or "relaxed" (opt-in: hardware sqrt / rsq, FMA contraction; results within ~1e-6)."""
+        self._ck(self._L.dcsg_set_numerics(self._h, {"exact": 0, "relaxed": 1}[mode]))
+
     # ---- Evaluator::build (Evaluator.cpp:45-112) -------------------------------------------
     def build(self, scene_txt, buildprocedure_txt, scene_cl=None, arbitrary_data=None):
         ad = None

@@ -93,6 +93,13 @@ const char* dcsg_last_error(const dcsg_ctx* ctx);
  * like Evaluator::build returning (-1, log). */
 int dcsg_load_scene(dcsg_ctx* ctx, const char* scene_txt, const char* buildprocedure_txt, const char* scene_cl,
                     const float* arbitrary_data, size_t n_arbitrary);
+/* Arithmetic of the scenes loaded AFTER this call (no reference counterpart; default DCSG_NUMERICS_EXACT).
+ * EXACT: IEEE operations in the reference's order, bit-identical to the oracle.  RELAXED (opt-in): hardware square
+ * root and reciprocal square root (1 ulp), FMA contraction, float-only normals -- faster, results within ~1e-6 of the
+ * exact ones (tests/test_gpu_relaxed.py holds SDF values, normals and exported vertices to 1e-5). */
+#define DCSG_NUMERICS_EXACT 0
+#define DCSG_NUMERICS_RELAXED 1
+int dcsg_set_numerics(dcsg_ctx* ctx, int mode);
 /* Evaluator::setArbitraryData (Evaluator.cpp:213-225): copies `items` floats, uploads the whole table. */
 int dcsg_set_arbitrary_data(dcsg_ctx* ctx, const float* data, size_t items);
 /* Scene facts after loading: object / build-step counts, interpreter registers in use, whether scene.cl
@@ -149,6 +156,17 @@ int dcsg_copy_triangles_device(dcsg_ctx* ctx, float* d_out, uint64_t max_triangl
 /* cms::writeTrianglesToSTL (utils.hpp:41-103) / writeTrianglesToPLY (utils.hpp:106-154). */
 int dcsg_write_stl(const char* path, const float* triangles, uint64_t n_triangles);
 int dcsg_write_ply(const char* path, const float* triangles, uint64_t n_triangles);
+/* Byte-range forms for sharded exports (one process per GPU): both formats are fixed-size records once
+ * the total count is known, so every rank writes triangles [first, first + n) of a file of `total` triangles at their
+ * final offsets.  flags: DCSG_WRITE_BEGIN -- create / open for overwrite, mark the file incomplete and reserve its
+ * size (one rank, before any payload; then a barrier); DCSG_WRITE_END -- cut the file to its final length and write
+ * the real header (one rank, after a barrier behind all payload).  dcsg_write_stl(path, t, n) is
+ * dcsg_write_stl_range(path, t, n, 0, n, BEGIN | END).  A file is valid only after END (crash safety: a failed or
+ * interrupted export never leaves a valid header over a stale body). */
+#define DCSG_WRITE_BEGIN 1u
+#define DCSG_WRITE_END 2u
+int dcsg_write_stl_range(const char* path, const float* triangles, uint64_t n, uint64_t first, uint64_t total, unsigned flags);
+int dcsg_write_ply_range(const char* path, const float* triangles, uint64_t n, uint64_t first, uint64_t total, unsigned flags);
 /* Opt-in writers beyond the reference's (its STL has zero normals, its PLY repeats every vertex per face):
  * STL with facet normals normalize(cross(B-A, C-A)) of the vertices as written; PLY with every distinct
  * position once (float x y z, order of first appearance) and faces indexing them. */
@@ -202,6 +220,10 @@ int dcsg_jit_prebuild(const char* scene_cl, char* log_out, size_t log_cap, int* 
  * the specialisation of its build procedure), if it needs one. */
 int dcsg_jit_prebuild_scene(const char* scene_txt, const char* buildprocedure_txt, const char* scene_cl, char* log_out,
                             size_t log_cap, int* from_cache);
+
+/* ... with the arithmetic of dcsg_set_numerics. */
+int dcsg_jit_prebuild_scene_numerics(const char* scene_txt, const char* buildprocedure_txt, const char* scene_cl,
+                                     int numerics, char* log_out, size_t log_cap, int* from_cache);
 
 #ifdef __cplusplus
 }

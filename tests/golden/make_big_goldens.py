@@ -17,7 +17,10 @@ TABLE = O.LookupTable(open(os.path.join(HERE, "..", "..", "designcsg_amd", "data
 RUNS = {"sphere_6_8_9": ("sphere", (6, 8, 9)), "design2_6_8_9": ("design2", (6, 8, 9)),
         "design2_7_9_10": ("design2", (7, 9, 10)), "flat256_6_8_9": ("flat256", (6, 8, 9)),
         "grouped256_6_8_9": ("grouped256", (6, 8, 9)),
-        "smooth256_6_8_9": ("smooth256", (6, 8, 9))}   # smooth-join extension: oracle-defined, no reference figure
+        "smooth256_6_8_9": ("smooth256", (6, 8, 9)),   # smooth-join extension: oracle-defined, no reference figure
+        # BASELINE config 5 at its stated size (1024^3, levels 7/9/10)
+        "flat256_7_9_10": ("flat256", (7, 9, 10)), "grouped256_7_9_10": ("grouped256", (7, 9, 10)),
+        "smooth256_7_9_10": ("smooth256", (7, 9, 10))}   # extension, as above
 
 
 def tri_set_hash(tris):

@@ -191,6 +191,57 @@ def test_writers_byte_identical_to_oracle(built_lib, oracle, tmp_path):
         assert ply.startswith(hdr) and len(ply) == len(hdr) + 85 * n
 
 
+def test_range_writers_and_crash_safety(built_lib, tmp_path):
+    """dcsg_write_{stl,ply}_range (what the ranks of a sharded export call): any partition of the triangles, written in
+    any order between BEGIN and END, gives the single-shot file byte for byte; between BEGIN and END the file does not
+    look like a finished STL / PLY; a failed write leaves an empty file (never a valid header over a stale body)."""
+    from designcsg_amd.evaluator import write_ply, write_stl
+    rng = np.random.default_rng(3)
+    n = 70000  # more than one writer buffer, more than one thread
+    tris = rng.normal(size=(n, 3, 3)).astype(np.float32)
+    write_stl(tmp_path / "whole.stl", tris)
+    write_ply(tmp_path / "whole.ply", tris)
+    cuts = [0, 1, 12345, 12345, 50000, n]  # includes an empty range
+    order = [3, 0, 4, 2, 1]
+    for ext, fn in (("stl", built_lib.dcsg_write_stl_range), ("ply", built_lib.dcsg_write_ply_range)):
+        path = tmp_path / ("parts." + ext)
+        # a longer stale file of the same name: the tail must go, and no reader may see old + new mixed as valid
+        (tmp_path / ("whole." + ext)).read_bytes()
+        path.write_bytes((tmp_path / ("whole." + ext)).read_bytes() + b"stale tail" * 1000)
+        assert fn(os.fsencode(path), None, 0, 0, n, 1) == 0                      # BEGIN
+        head = path.read_bytes()[:40]
+        assert head.startswith(b"dcsg: incomplete export")
+        for k in order:
+            a, b = cuts[k], cuts[k + 1]
+            part = np.ascontiguousarray(tris[a:b])
+            assert fn(os.fsencode(path), part.ctypes.data_as(C.c_void_p) if b > a else None, b - a, a, n, 0) == 0
+            assert path.read_bytes()[:23] == b"dcsg: incomplete export"            # still not a finished file
+        assert fn(os.fsencode(path), None, 0, 0, n, 2) == 0                      # END
+        assert path.read_bytes() == (tmp_path / ("whole." + ext)).read_bytes()
+        # argument checks: range beyond the total; payload into a file that was never begun
+        assert fn(os.fsencode(path), tris.ctypes.data_as(C.c_void_p), 10, n - 5, n, 0) != 0
+        assert fn(os.fsencode(tmp_path / ("never." + ext)), tris.ctypes.data_as(C.c_void_p), 10, 0, n, 0) != 0
+    # a write that fails part-way (file size limit) leaves an empty file behind
+    code = (
+        "import resource, signal, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from designcsg_amd.evaluator import write_stl, write_ply\n"
+        "from designcsg_amd._lib import DcsgError\n"
+        "signal.signal(signal.SIGXFSZ, signal.SIG_IGN)\n"
+        "resource.setrlimit(resource.RLIMIT_FSIZE, (1 << 20, 1 << 20))\n"
+        "t = np.ones((100000, 3, 3), dtype=np.float32)\n"
+        "for f, w in ((%r, write_stl), (%r, write_ply)):\n"
+        "    try:\n"
+        "        w(f, t)\n"
+        "        sys.exit(3)\n"
+        "    except DcsgError:\n"
+        "        pass\n" % (ROOT, str(tmp_path / "whole.stl"), str(tmp_path / "whole.ply")))
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.path.getsize(tmp_path / "whole.stl") == 0 and os.path.getsize(tmp_path / "whole.ply") == 0
+
+
 def test_lookup_table_expansion_matches_oracle(built_lib, lookup_table):
     table = np.zeros(4096, dtype=np.uint8)
     total = C.c_int()
@@ -326,6 +377,38 @@ def test_program_optimiser_preserves_values(built_lib, oracle, name):
     imp = object_values(oracle, sc, pts)
     assert np.array_equal(run_register_program(reg, n_regs, imp, len(pts)).view(np.uint32), want.view(np.uint32))
     assert np.array_equal(run_stack_program(stk, imp, len(pts)).view(np.uint32), want.view(np.uint32))
+
+
+def test_unknown_opcodes_are_dropped_before_their_operands_are_looked_at(built_lib):
+    """k2.cl's switch ignores opcodes it does not know (k2.cl:59-140).  The numbers 16-21 and 32-46 are the HOST's own
+    fused / stack opcodes: a file carrying them (with operands far outside every table) must compile to exactly the
+    program of the same file without those lines -- nothing indexes with their slots or objects."""
+    import ctypes as C
+    scene_txt = read_scene("mixed_groups")["scene.txt"]
+    clean = "0 0 0 0\n0 2 1 1\n2 0 1 0\n1 0 -1 -1"
+    junk_ops = list(range(9, 64)) + [-1, -7, 255, 1000, 2 ** 31 - 1]
+    dirty = ["0 0 0 0"]
+    for i, op in enumerate(junk_ops):
+        dirty.append("%d %d %d %d" % (op, 2, 5000 + i, (-1) ** i * (5000 + 17 * i)))
+    dirty += ["0 2 1 1", "16 2 0 5000", "2 0 1 0", "35 4 99999 -12345", "1 0 -1 -1", "46 0 0 70000"]
+
+    def compile_(bp):
+        cap = 256
+        reg, stk = (C.c_int32 * (4 * cap))(), (C.c_int32 * (4 * cap))()
+        n_reg, n_regs, n_stk, depth = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        rc = built_lib.dcsg_compile_program(scene_txt.encode(), bp.encode(), reg, C.byref(n_reg), C.byref(n_regs), stk,
+                                            C.byref(n_stk), C.byref(depth), cap)
+        assert rc == 0, built_lib.dcsg_last_error(None)
+        return list(reg[:4 * n_reg.value]), n_regs.value, list(stk[:4 * n_stk.value]), depth.value
+
+    assert compile_("\n".join(dirty)) == compile_(clean)
+    # known opcodes with bad operands are still rejected, not ignored
+    cap = 16
+    buf = (C.c_int32 * (4 * cap))()
+    z = C.c_int()
+    for bad in ("0 2 1 64\n1 0 -1 -1", "0 2 999 0\n1 0 -1 -1", "2 0 77 0\n1 0 -1 -1", "1 -3 -1 -1"):
+        assert built_lib.dcsg_compile_program(scene_txt.encode(), bad.encode(), buf, C.byref(z), C.byref(z), buf, C.byref(z),
+                                              C.byref(z), cap) != 0, bad
 
 
 def test_program_optimiser_on_hand_written_programs(built_lib, oracle):

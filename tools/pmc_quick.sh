@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/pmcq_$TAG
 mkdir -p $OUT
 CTRS=${DCSG_PMC:-"SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR"}
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -o sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-export "$@" > /dev/null 2> $OUT/err.txt || exit 1
+rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -o sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-export --no-secondary "$@" > /dev/null 2> $OUT/err.txt || exit 1
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
