@@ -64,8 +64,8 @@ def build_ref(force=False):
     tree is present (the build container; the built file travels to the GPU box).  Returns the path or None."""
     if not os.path.isdir(REFERENCE):
         return REF_LIB if os.path.exists(REF_LIB) else None
-    shim = os.path.join(HERE, "ref_shim.cpp")
-    if force or not os.path.exists(REF_LIB) or os.path.getmtime(REF_LIB) < os.path.getmtime(shim):
+    shims = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "ref_isv_shim.cpp", "Makefile")]
+    if force or not os.path.exists(REF_LIB) or os.path.getmtime(REF_LIB) < max(os.path.getmtime(f) for f in shims):
         subprocess.run(["make", "-C", HERE, "-s", "ref"], check=True)
     return REF_LIB
 

@@ -2,9 +2,10 @@
 
 oracle/_ref/libdcsg_ref.so (oracle/Makefile target `ref`, built by __graft_entry__.build() wherever /root/reference
 exists; the built file travels to the GPU box) wraps the reference's stand-alone headers -- utils.hpp (both writers),
-readLookupTable.hpp, geometry.hpp, octree.hpp -- without any stand-in.  Its mesher, ISV cache and Evaluator cannot be
-built here (wx / Win32 headers, OpenCL runtime), so those parts of the oracle stay pinned by the survey's golden
-vectors (tests/test_oracle_golden.py)."""
+readLookupTable.hpp, geometry.hpp, octree.hpp -- and its lattice cache ISV::ISV3D64 (ISV.hpp, instantiated as the export
+driver does; oracle/ref_isv_shim.cpp) without any stand-in header or library.  Its mesher and Evaluator cannot be built
+here (wx / Win32 headers, OpenCL runtime), so those parts of the oracle stay pinned by the survey's golden vectors
+(tests/test_oracle_golden.py)."""
 import ctypes as C
 import os
 
@@ -29,11 +30,94 @@ def ref():
     L.ref_angle_between.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
     L.ref_magnitude.restype = C.c_float
     L.ref_magnitude.argtypes = [C.c_void_p]
+    L.ref_isv_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_ulonglong, C.c_void_p]
+    L.ref_isv_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_ulonglong, C.c_void_p]
+    L.ref_isv_values.restype = C.c_longlong
+    L.ref_isv_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_ulonglong,
+                                 ISV_EVAL, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
 
 
 def p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+ISV_EVAL = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_ulonglong, C.POINTER(C.c_float), C.c_void_p)
+
+# lattice boxes: the reference's own stage-A results for Sphere and Design2 ("nice": multiples of 10/256), a box that is
+# nothing of the sort, and a non-cubic one (ISV3D64 takes three diameters; the export always passes a cube)
+ISV_BOXES = [([0.0, 0.0, 0.0], [5.3515625] * 3), ([0.0, -0.0390625, 0.0], [9.3359375] * 3),
+             ([0.1, -0.2, 0.3], [7.3, 7.3, 7.3]), ([-1.25, 0.5, 2.0], [3.0, 11.7, 6.1])]
+
+
+def isv_query_points(center, diam, res, rng, n=4000):
+    """What the mesher asks for (octree corners: dyadic fractions of the box, including the maximum corner = index res),
+    lattice points themselves, points next to cell boundaries, and arbitrary points inside the box."""
+    c, d = np.float32(center), np.float32(diam)
+    lo = c - d * np.float32(0.5)
+    frac = rng.integers(0, res + 1, size=(n, 3)).astype(np.float32) / np.float32(res)
+    pts = [lo + d * frac,
+           lo + d * rng.random((n, 3), dtype=np.float32),
+           np.nextafter(lo + d * frac, np.float32(np.inf)), np.nextafter(lo + d * frac, np.float32(-np.inf)),
+           np.array([c + d * np.float32(0.5), c - d * np.float32(0.5), c], dtype=np.float32)]
+    return np.ascontiguousarray(np.concatenate(pts).astype(np.float32))
+
+
+@pytest.mark.parametrize("res", [128, 512, 1024])
+def test_lattice_snap_and_positions_equal_the_reference_isv(ref, oracle, res):
+    """ISV3D64::getCoords (ISV.hpp:91-96, the truncating snap every mesher sample goes through) and getPoint
+    (:103-109), bit for bit: the oracle's oracle_lattice_coords / oracle_lattice_point against the reference's class."""
+    rng = np.random.default_rng(res)
+    for center, diam in ISV_BOXES:
+        pts = isv_query_points(center, diam, res, rng)
+        want = np.zeros((len(pts), 3), dtype=np.int64)
+        cf, df = np.float32(center), np.float32(diam)
+        ref.ref_isv_coords(p(cf), p(df), res, 16, p(pts), len(pts), p(want))
+        got = np.array([oracle.lattice_coords(center, diam, res, q) for q in pts[::7]])
+        assert np.array_equal(got, want[::7])
+        assert want.min() >= -1 and want.max() <= res + 1 and (want == res).any()   # index res is reachable (quirk 5)
+        idx = np.ascontiguousarray(np.stack([np.arange(res + 1)] * 3, axis=1).astype(np.int32))
+        idx[:, 1] = idx[::-1, 1]
+        want_p = np.zeros((res + 1, 3), dtype=np.float32)
+        ref.ref_isv_points(p(cf), p(df), res, p(idx), len(idx), p(want_p))
+        got_p = np.array([oracle.lattice_point(center, diam, res, *map(int, t)) for t in idx])
+        assert np.array_equal(got_p.view(np.uint32), want_p.view(np.uint32))
+
+
+def test_lattice_value_is_the_value_at_the_snapped_point(ref, oracle):
+    """ISV3D64::getValue (ISV.hpp:15-60) returns the data source's value AT THE SNAPPED LATTICE POINT -- block key
+    (:85-87), block point order (:28-33), in-block index (:97-102, quirk 7), the block beyond the box for index res
+    (quirk 5), eviction and re-fetch (:110-124) included.  The oracle's sampler is 'evaluate at
+    lattice_point(clamp(lattice_coords(p)))': both the point and the value must agree bit for bit."""
+    res, sub = 128, 16
+    rng = np.random.default_rng(5)
+    f = lambda q: (q[:, 0] * np.float32(1.25) + q[:, 1] * np.float32(-0.75)) + q[:, 2] * np.float32(3.5)
+    calls = []
+
+    @ISV_EVAL
+    def source(xyz, n, out, user):
+        q = np.ctypeslib.as_array(xyz, shape=(n, 3))
+        np.ctypeslib.as_array(out, shape=(n,))[:] = f(q)
+        calls.append(int(n))
+
+    for center, diam in ISV_BOXES[:3]:
+        pts = isv_query_points(center, diam, res, rng, n=150)
+        # only points the mesher can produce: inside the closed box (coords 0..res)
+        cf, df = np.float32(center), np.float32(diam)
+        co = np.zeros((len(pts), 3), dtype=np.int64)
+        ref.ref_isv_coords(p(cf), p(df), res, sub, p(pts), len(pts), p(co))
+        pts = np.ascontiguousarray(pts[((co >= 0) & (co <= res)).all(1)])
+        for gc in (-1, 8):   # the export's "never collect" and an aggressive collector: the values cannot depend on it
+            del calls[:]
+            values = np.zeros(len(pts), dtype=np.float32)
+            at = np.zeros((len(pts), 3), dtype=np.float32)
+            blocks = ref.ref_isv_values(p(cf), p(df), res, sub, 16, gc, p(pts), len(pts), source, None, p(values), p(at))
+            assert blocks == len(calls) and all(n == (res // sub) ** 3 for n in calls)
+            want_at = np.array([oracle.lattice_point(center, diam, res,
+                                                     *np.clip(oracle.lattice_coords(center, diam, res, q), 0, res))
+                                for q in pts])
+            assert np.array_equal(at.view(np.uint32), want_at.view(np.uint32))
+            assert np.array_equal(values.view(np.uint32), f(want_at).astype(np.float32).view(np.uint32))
 
 
 def test_writers_equal_the_reference_writers(ref, oracle, built_lib, tmp_path):
