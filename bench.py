@@ -5,13 +5,14 @@ Metric (BASELINE.json): Mvoxels/s of SDF+normal evaluation.  A step is one sweep
 (res+1)^3 lattice of the workload into buffers resident in HBM; voxels = res^3.  Default workload
 is BASELINE config 2 (single sphere, 512^3, box from the reference's own stage-A estimate).
 
-N > 1 (one process per GPU, torch.distributed over RCCL), default `--scaling weak`: the domain is N
-lattice boxes of the workload's size stacked along z (rank r's box is the workload's box shifted by
-r diameters), i.e. one long lattice cut into N Z slabs of (res+1)^2 x res points; every rank sweeps its
-slab and receives the boundary plane it shares with its upper neighbour over RCCL send/recv -- the one
-plane a slab's mesher needs beyond its own, and the only exchange the path has.
-Per-GPU work is fixed, value = N * res^3 voxels / time.  `--scaling strong` shards the single
-workload lattice into N thinner Z slabs instead (total work fixed).
+N > 1 (one process per GPU, torch.distributed over RCCL), default `--scaling strong` on the 1024^3 sphere lattice (the
+other size BASELINE.json's metric is quoted on): ONE fixed lattice cut into N Z slabs; every rank
+sweeps its slab and receives the boundary plane it shares with its upper neighbour over RCCL send/recv -- the one plane a
+slab's mesher needs beyond its own, and the only exchange the path has.  Total work is fixed, value = res^3 voxels /
+time (max over ranks); rank 0 also times the same lattice on its own GPU afterwards (`single_gpu_same_workload`), so
+that the line carries the speed-up for the SAME workload.  `--scaling weak` stacks one workload-sized box per rank along
+z instead (per-GPU work fixed, value = N * res^3 / time).  `--workload design2_1024` is BASELINE config 4's scene
+(compute-bound: 75 ms per sweep on one GPU).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -213,15 +214,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="sphere512", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: sphere512 on one GPU (BASELINE config 2), sphere1024 on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary sweep lines (LDS-table interpreter, "
                     "relaxed numerics, 1024^3)")
     ap.add_argument("--no-export", action="store_true", help="skip the export wall-clock lines (second half of the metric)")
     ap.add_argument("--verify-halo", action="store_true", help="after the timed loop, check the received halo plane")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = one workload-sized lattice box per rank, stacked along z (default); "
-                         "strong = the single workload lattice split into N Z slabs")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N>1: strong = the single workload lattice split into N Z slabs (default); "
+                         "weak = one workload-sized lattice box per rank, stacked along z")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default, what the driver runs); gloo = rehearsal of the N>1 logic on "
                          "a box with fewer GPUs than ranks: halo planes are staged through host memory")
@@ -247,6 +249,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if args.workload is None:
+        args.workload = "sphere512" if world == 1 else "sphere1024"
     scene, grid_level, center, diameter = WORKLOADS[args.workload]
     scene_dir = os.path.join(ROOT, "tests", "golden", "scenes", scene)
     res = 1 << grid_level
@@ -369,6 +373,12 @@ def main():
                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "Mvoxels_per_s": round(res ** 3 / (ms * 1e-3) / 1e6, 1),
                     "algorithmic_bytes_per_launch": 4 * (own_hi - lo) * plane}
+    # N > 1, strong scaling: the same lattice on rank 0's GPU alone (outside the timed region; the other ranks wait)
+    single = None
+    if world > 1 and not weak:
+        if rank == 0:
+            single = time_sweeps(ev, center, diameter, res, reps=max(3, min(args.steps, 10)))["fused"]
+        dist.barrier()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         if args.backend == "gloo":
@@ -400,6 +410,9 @@ def main():
                          "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT * own_points},
         }
+        if single:
+            out["single_gpu_same_workload"] = dict(single, speedup=round(value / single["Mvoxels_per_s"], 3),
+                                                   note="the same %d^3 lattice swept by rank 0's GPU alone (kernel time)" % n1)
         if sdf_only:
             out["sdf_only_sweep"] = sdf_only
         tr = profiled_traffic(kernel, workload) if world == 1 else None

@@ -1355,6 +1355,161 @@ int dcsg_expand_lookup_table(const char* txt, uint8_t table[4096], int* total)
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Stages A .. projection of the export for Z slab `rank` of `world` (world = 1: the whole box).  Rank r owns the octree
+// nodes whose lowest lattice plane lies in [r res/world, (r+1) res/world); coarse nodes that straddle
+// slabs are classified by every rank from on-demand samples.  The lattice planes a slab's nodes read, including the
+// plane it shares with the slab above, are evaluated by this rank itself (a sample is a pure function of its lattice
+// index), so this entry point needs no exchange; the RCCL halo exchange of the dense-sweep path lives in
+// designcsg_amd/sharded.py.  Triangles stay in the context's buffer.
+int export_mesh_stage(dcsg_ctx* c, const dcsg_export_config& cfg, int rank, int world, unsigned flags, dcsg_export_stats& st)
+{
+    int r;
+    double t0 = now_s();
+    // stage A (every rank: 0.2 ms, no communication)
+    float diameter = 0;
+    if ((r = dcsg_estimate_bounding_box(c, cfg.bounding_box_half_diameter, st.box_center, &diameter, &st.interior_points)))
+        return r;
+    st.box_diameter = diameter;
+    st.t_bbox = now_s() - t0;
+    if (!(diameter > 0)) return fail(c, DCSG_ERR_INVALID, "bounding-box estimate is empty");
+
+    t0 = now_s();
+    if (cfg.grid_level < 1 || cfg.grid_level > 12) return fail(c, DCSG_ERR_INVALID, "gridLevel out of range");
+    const int res = 1 << cfg.grid_level;
+    if (world < 1 || rank < 0 || rank >= world || res % world != 0)
+        return fail(c, DCSG_ERR_INVALID, "the lattice does not split into that many equal Z slabs");
+    const int z_own_lo = rank * (res / world), z_own_hi = (rank + 1) * (res / world);
+    const size_t n1 = (size_t)res + 1, plane = n1 * n1, n_pts = n1 * plane;
+    const size_t slab_pts = (size_t)(z_own_hi - z_own_lo + 1) * plane;  // own planes + the shared upper one
+    st.lattice_points = n_pts;
+    // Normals: swept densely with the SDF, or evaluated on demand by the mesher (its samples go through the generic
+    // interpreter, which visits every object).  Many-object scenes that run the culling kernels sweep densely:
+    // flat256 at 512^3 meshes in 0.8 ms after a 9.5 ms fused sweep instead of 37 ms after a 6 ms SDF sweep.
+    const bool dense_normals = (flags & DCSG_EXPORT_DENSE_NORMALS) != 0 ||
+                               (c->variant == 4 && !(flags & DCSG_EXPORT_SPARSE_NORMALS));
+    if ((r = ensure(c, c->d_lat_sdf, slab_pts * sizeof(float)))) return r;
+    if (dense_normals && (r = ensure(c, c->d_lat_nrm, slab_pts * 3 * sizeof(float)))) return r;
+    // the kernels index the lattice by absolute plane: the slab buffer stands for planes z_own_lo .. z_own_hi
+    float* sdf0 = (float*)((uintptr_t)c->d_lat_sdf.p - (uintptr_t)z_own_lo * plane * sizeof(float));
+    float* nrm0 = dense_normals ? (float*)((uintptr_t)c->d_lat_nrm.p - (uintptr_t)z_own_lo * plane * 3 * sizeof(float)) : nullptr;
+    float diam3[3] = {diameter, diameter, diameter};
+    // Node-wise sweep (default): the mesher's first levels sample on demand; at level max(min,2) -- the first whose
+    // nodes the cull rule can drop for good -- the lattice is evaluated inside the nodes that are still alive, which
+    // is everything later levels can read (a sample outside them, should rounding ever produce one, is evaluated on
+    // demand: dcsg_lattice_point_written).  Worth it while a node is a small block; otherwise, or on request, the
+    // whole slab is swept.  A node of the sweep level must not straddle slabs: 2^level >= world.
+    const int sweep_level = cfg.min_level > 2 ? cfg.min_level : 2;
+    const bool node_wise = !(flags & DCSG_EXPORT_DENSE_SWEEP) && !getenv("DCSG_DENSE_SWEEP") && sweep_level <= cfg.max_level &&
+                           cfg.grid_level - sweep_level <= 4 && cfg.grid_level - sweep_level >= 0 && (1 << sweep_level) >= world;
+    uint64_t n_tris = 0;
+    if (node_wise) {
+        NodeSweep ns;
+        ns.level = sweep_level;
+        ns.d_sdf = sdf0;
+        ns.d_nrm = nrm0;
+        if ((r = mesh_impl(c, st.box_center, diameter, &cfg, nullptr, nullptr, 0, res, z_own_lo, z_own_hi, &n_tris, &st.mesh, c->stream, &ns)))
+            return r;
+        st.sweep_kernel_ms = ns.ms;
+        // candidates the cull rule dropped are not swept; they are exactly the nodes counted as culled at that level
+        st.swept_nodes = ns.nodes - st.mesh.culled[ns.level];
+        st.swept_points = ns.nodes ? ns.points / ns.nodes * st.swept_nodes : 0;
+        st.t_sweep = ns.ms * 1e-3;
+        st.t_mesh = now_s() - t0 - st.t_sweep;
+    } else {
+        // one launch covers < 2^32 points; sweep in Z ranges when the slab is larger
+        const int planes_per = (int)(0xf0000000ull / plane) > 0 ? (int)(0xf0000000ull / plane) : 1;
+        double sweep_ms = 0;
+        for (int z0 = z_own_lo; z0 <= z_own_hi; z0 += planes_per) {
+            int z1 = z0 + planes_per < z_own_hi + 1 ? z0 + planes_per : z_own_hi + 1;
+            float* sd = sdf0 + (size_t)z0 * plane;
+            float* nr = dense_normals ? nrm0 + (size_t)z0 * plane * 3 : nullptr;
+            if ((r = sweep_device(c, st.box_center, diam3, res, z0, z1, sd, nr, c->stream, true))) return r;
+            double ms = 0;
+            if ((r = dcsg_last_sweep_ms(c, &ms))) return r;
+            sweep_ms += ms;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        st.sweep_kernel_ms = sweep_ms;
+        st.swept_points = slab_pts;
+        st.t_sweep = now_s() - t0;
+
+        // mesher (retopologize = identity: the reference's is undefined behaviour, see DESIGN.md)
+        t0 = now_s();
+        if ((r = dcsg_mesh_lattice_device(c, st.box_center, diameter, &cfg, (const float*)c->d_lat_sdf.p,
+                                          dense_normals ? (const float*)c->d_lat_nrm.p : nullptr, z_own_lo, z_own_hi, z_own_lo,
+                                          z_own_hi, &n_tris, &st.mesh, c->stream)))
+            return r;
+        st.t_mesh = now_s() - t0;
+    }
+    st.triangles = n_tris;
+
+    t0 = now_s();
+    if ((r = dcsg_project_triangles(c, cfg.gradient_descent_steps, c->stream))) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    st.t_project = now_s() - t0;
+    return 0;
+}
+
+// triangles of the context -> pinned host staging buffer (kept across exports: PCIe rate instead of pageable rate)
+int stage_triangles_on_host(dcsg_ctx* c, float** host)
+{
+    size_t need = (size_t)c->n_tris * 9 * sizeof(float) + 64;
+    if (need > c->h_pinned_cap) {
+        if (c->h_pinned) hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr;
+        c->h_pinned_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_pinned, need + need / 4, hipHostMallocDefault));
+        c->h_pinned_cap = need + need / 4;
+    }
+    *host = (float*)c->h_pinned;
+    return dcsg_download_triangles(c, *host, c->n_tris);
+}
+
+}  // namespace
+
+extern "C" {
+
+// One Z slab of the export, stages A .. projection (no files): what each rank of a sharded export runs.
+int dcsg_export_slab(dcsg_ctx* c, const char* cfg_txt, int rank, int world, unsigned flags, dcsg_export_stats* stats)
+{
+    int r = need_scene(c);
+    if (r) return r;
+    dcsg_export_config cfg;
+    std::string err;
+    if (!parse_export_config(cfg_txt, cfg, err)) return fail(c, DCSG_ERR_INVALID, err);
+    dcsg_export_stats st;
+    memset(&st, 0, sizeof(st));
+    double t_start = now_s();
+    if ((r = export_mesh_stage(c, cfg, rank, world, flags, st))) return r;
+    st.t_total = now_s() - t_start;
+    if (stats) *stats = st;
+    return 0;
+}
+
+// The slab's triangles into the files at their final offsets (dcsg_write_*_range): triangles [first, first + own) of
+// `total`.  flags: DCSG_WRITE_BEGIN / DCSG_WRITE_END as for the range writers (rank 0, around barriers).
+int dcsg_write_slab(dcsg_ctx* c, const char* stl_path, const char* ply_path, uint64_t first, uint64_t total, unsigned flags)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    float* host = nullptr;
+    int r = 0;
+    if (c->n_tris && (stl_path || ply_path) && (r = stage_triangles_on_host(c, &host))) return r;
+    int rc_stl = 0, rc_ply = 0;
+    std::thread ply_thread;
+    const uint64_t n = c->n_tris;
+    if (ply_path) ply_thread = std::thread([&] { rc_ply = dcsg_write_ply_range(ply_path, host, n, first, total, flags); });
+    if (stl_path) rc_stl = dcsg_write_stl_range(stl_path, host, n, first, total, flags);
+    if (ply_thread.joinable()) ply_thread.join();
+    if (rc_stl) return fail(c, rc_stl, "cannot write STL");
+    if (rc_ply) return fail(c, rc_ply, "cannot write PLY");
+    return 0;
+}
+
 // MyFrame::OnExportInner, DesignCSG.cpp:638-790
 int dcsg_export(dcsg_ctx* c, const char* cfg_txt, const char* stl_path, const char* ply_path, unsigned flags,
                 dcsg_export_stats* stats)
@@ -1366,99 +1521,14 @@ int dcsg_export(dcsg_ctx* c, const char* cfg_txt, const char* stl_path, const ch
     if (!parse_export_config(cfg_txt, cfg, err)) return fail(c, DCSG_ERR_INVALID, err);
     dcsg_export_stats st;
     memset(&st, 0, sizeof(st));
-    double t_start = now_s(), t0 = t_start;
-
-    // stage A
-    float diameter = 0;
-    if ((r = dcsg_estimate_bounding_box(c, cfg.bounding_box_half_diameter, st.box_center, &diameter,
-                                        &st.interior_points)))
-        return r;
-    st.box_diameter = diameter;
-    st.t_bbox = now_s() - t0;
-    if (!(diameter > 0)) return fail(c, DCSG_ERR_INVALID, "bounding-box estimate is empty");
-
-    // dense lattice: every sample the reference's ISV caches would ever hold, evaluated once
-    t0 = now_s();
-    if (cfg.grid_level < 1 || cfg.grid_level > 12) return fail(c, DCSG_ERR_INVALID, "gridLevel out of range");
-    const int res = 1 << cfg.grid_level;
-    const size_t n1 = (size_t)res + 1, n_pts = n1 * n1 * n1;
-    st.lattice_points = n_pts;
-    // Normals: swept densely with the SDF, or evaluated on demand by the mesher (its samples go through the generic
-    // interpreter, which visits every object).  Many-object scenes that run the culling kernels sweep densely:
-    // flat256 at 512^3 meshes in 0.8 ms after a 9.5 ms fused sweep instead of 37 ms after a 6 ms SDF sweep.
-    const bool dense_normals = (flags & DCSG_EXPORT_DENSE_NORMALS) != 0 ||
-                               (c->variant == 4 && !(flags & DCSG_EXPORT_SPARSE_NORMALS));
-    if ((r = ensure(c, c->d_lat_sdf, n_pts * sizeof(float)))) return r;
-    if (dense_normals && (r = ensure(c, c->d_lat_nrm, n_pts * 3 * sizeof(float)))) return r;
-    float diam3[3] = {diameter, diameter, diameter};
-    // Node-wise sweep (default): the mesher's first levels sample on demand; at level max(min,2) -- the first whose
-    // nodes the cull rule can drop for good -- the lattice is evaluated inside the nodes that are still alive, which
-    // is everything later levels can read (a sample outside them, should rounding ever produce one, is evaluated on
-    // demand: dcsg_lattice_point_written).  Worth it while a node is a small block; otherwise, or on request, the
-    // whole lattice is swept.
-    const int sweep_level = cfg.min_level > 2 ? cfg.min_level : 2;
-    const bool node_wise = !(flags & DCSG_EXPORT_DENSE_SWEEP) && !getenv("DCSG_DENSE_SWEEP") && sweep_level <= cfg.max_level &&
-                           cfg.grid_level - sweep_level <= 4 && cfg.grid_level - sweep_level >= 0;
-    uint64_t n_tris = 0;
-    if (node_wise) {
-        NodeSweep ns;
-        ns.level = sweep_level;
-        ns.d_sdf = (float*)c->d_lat_sdf.p;
-        ns.d_nrm = dense_normals ? (float*)c->d_lat_nrm.p : nullptr;
-        if ((r = mesh_impl(c, st.box_center, diameter, &cfg, nullptr, nullptr, 0, res, 0, res, &n_tris, &st.mesh, c->stream, &ns)))
-            return r;
-        st.sweep_kernel_ms = ns.ms;
-        // candidates the cull rule dropped are not swept; they are exactly the nodes counted as culled at that level
-        st.swept_nodes = ns.nodes - st.mesh.culled[ns.level];
-        st.swept_points = ns.nodes ? ns.points / ns.nodes * st.swept_nodes : 0;
-        st.t_sweep = ns.ms * 1e-3;
-        st.t_mesh = now_s() - t0 - st.t_sweep;
-    } else {
-        // one launch covers < 2^32 points; sweep in Z ranges when the lattice is larger
-        const int planes_per = (int)(0xf0000000ull / (n1 * n1)) > 0 ? (int)(0xf0000000ull / (n1 * n1)) : 1;
-        double sweep_ms = 0;
-        for (int z0 = 0; z0 < (int)n1; z0 += planes_per) {
-            int z1 = z0 + planes_per < (int)n1 ? z0 + planes_per : (int)n1;
-            float* sd = (float*)c->d_lat_sdf.p + (size_t)z0 * n1 * n1;
-            float* nr = dense_normals ? (float*)c->d_lat_nrm.p + (size_t)z0 * n1 * n1 * 3 : nullptr;
-            if ((r = sweep_device(c, st.box_center, diam3, res, z0, z1, sd, nr, c->stream, true))) return r;
-            double ms = 0;
-            if ((r = dcsg_last_sweep_ms(c, &ms))) return r;
-            sweep_ms += ms;
-        }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        st.sweep_kernel_ms = sweep_ms;
-        st.swept_points = n_pts;
-        st.t_sweep = now_s() - t0;
-
-        // mesher (retopologize = identity: the reference's is undefined behaviour, see DESIGN.md)
-        t0 = now_s();
-        if ((r = dcsg_mesh_lattice_device(c, st.box_center, diameter, &cfg, (const float*)c->d_lat_sdf.p,
-                                          dense_normals ? (const float*)c->d_lat_nrm.p : nullptr, 0, res, 0, res, &n_tris,
-                                          &st.mesh, c->stream)))
-            return r;
-        st.t_mesh = now_s() - t0;
-    }
-    st.triangles = n_tris;
-
-    t0 = now_s();
-    if ((r = dcsg_project_triangles(c, cfg.gradient_descent_steps, c->stream))) return r;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    st.t_project = now_s() - t0;
+    double t_start = now_s(), t0;
+    if ((r = export_mesh_stage(c, cfg, 0, 1, flags, st))) return r;
+    const uint64_t n_tris = st.triangles;
 
     if (stl_path || ply_path) {
         t0 = now_s();
-        // pinned staging buffer (kept across exports): the download runs at PCIe rate instead of pageable rate
-        size_t need = (size_t)n_tris * 9 * sizeof(float) + 64;
-        if (need > c->h_pinned_cap) {
-            if (c->h_pinned) hipHostFree(c->h_pinned);
-            c->h_pinned = nullptr;
-            c->h_pinned_cap = 0;
-            HIPCHK(c, hipHostMalloc(&c->h_pinned, need + need / 4, hipHostMallocDefault));
-            c->h_pinned_cap = need + need / 4;
-        }
-        float* host = (float*)c->h_pinned;
-        if ((r = dcsg_download_triangles(c, host, n_tris))) return r;
+        float* host = nullptr;
+        if ((r = stage_triangles_on_host(c, &host))) return r;
         st.t_download = now_s() - t0;
         t0 = now_s();
         int rc_stl = 0, rc_ply = 0;

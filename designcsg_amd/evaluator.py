@@ -206,6 +206,32 @@ class Evaluator:
         return st
 
 
+    def export_slab(self, export_config_txt, rank, world, dense_normals=False, dense_sweep=False):
+        """Z slab `rank` of `world` of the export, stages A .. projection; triangles stay on the device."""
+        st = ExportStats()
+        flags = (_lib.EXPORT_DENSE_NORMALS if dense_normals else 0) | (_lib.EXPORT_DENSE_SWEEP if dense_sweep else 0)
+        self._ck(self._L.dcsg_export_slab(self._h, export_config_txt.encode(), int(rank), int(world), flags, C.byref(st)))
+        return st
+
+    def write_slab(self, stl_path, ply_path, first, total, flags=0):
+        """This context's triangles as triangles [first, first + n) of files holding `total` (range writers)."""
+        self._ck(self._L.dcsg_write_slab(self._h, None if stl_path is None else os.fsencode(stl_path),
+                                         None if ply_path is None else os.fsencode(ply_path), int(first), int(total), int(flags)))
+
+
+WRITE_BEGIN, WRITE_END = 1, 2
+
+
+def write_range(path, tris, first, total, flags=0):
+    """dcsg_write_stl_range / dcsg_write_ply_range by file extension; tris may be None (BEGIN / END only)."""
+    fn = _lib.lib().dcsg_write_ply_range if str(path).endswith(".ply") else _lib.lib().dcsg_write_stl_range
+    t = None if tris is None else np.ascontiguousarray(tris, dtype=np.float32)
+    rc = fn(os.fsencode(path), None if t is None or t.size == 0 else _fptr(t), 0 if t is None else t.size // 9, int(first),
+            int(total), int(flags))
+    if rc:
+        raise DcsgError(rc, "cannot write " + str(path))
+
+
 def parse_export_config(text):
     cfg = ExportConfig()
     if _lib.lib().dcsg_parse_export_config(text.encode(), C.byref(cfg)) != 0:

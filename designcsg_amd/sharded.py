@@ -8,6 +8,12 @@ only data-path exchange (point-to-point send/recv between Z neighbours); coarse 
 straddle slabs are processed redundantly by every rank from on-demand samples.  Triangles are then
 gathered to rank 0 (counts by all_gather, payload by gather), which writes the files.
 
+Two drivers share that partition.  `sharded_export_files` (default of tools/export_multi_gpu.py) is the export as the
+single-GPU path runs it, per slab: node-wise sweep restricted to the slab's octree nodes (each rank evaluates the shared
+plane itself: a sample is a pure function of its lattice index, so no exchange is needed), projection, then all_gather of
+the triangle COUNTS only and every rank writes its own byte range of the .stl / .ply (fixed-size records).
+`sharded_export` is the dense-slab form with the halo plane travelling over RCCL and the triangles gathered to rank 0.
+
 The compute backend is an object with the four methods of `HipBackend`; the product always uses
 `HipBackend` (libdcsg_hip through the C ABI).  tests/test_sharded_gloo.py injects a CPU checker backend to
 run this driver's partition / halo / gather logic under gloo with world_size 2 -- there is no CPU
@@ -139,3 +145,73 @@ def sharded_export(backend, cfg, rank, world, dense_normals=False, group=None, c
         all_tris, counts = tris, [int(tris.shape[0])]
     return dict(triangles=None if all_tris is None else all_tris.cpu().numpy(), counts=counts,
                 box=(center, diameter, interior), stats=stats, slab=(lo, hi))
+
+
+class HipSlab:
+    """The MI355X path of sharded_export_files: libdcsg_hip's slab entry points on this rank's GPU."""
+
+    def __init__(self, evaluator, dense_normals=False, dense_sweep=False):
+        self.ev, self.kw = evaluator, dict(dense_normals=dense_normals, dense_sweep=dense_sweep)
+
+    def export_slab(self, cfg_txt, rank, world):
+        st = self.ev.export_slab(cfg_txt, rank, world, **self.kw)
+        return int(st.triangles), st
+
+    def write_slab(self, stl_path, ply_path, first, total):
+        self.ev.write_slab(stl_path, ply_path, first, total, 0)
+
+
+def sharded_export_files(slab, cfg_txt, rank, world, stl_path, ply_path, group=None):
+    """Every rank meshes and projects its Z slab, then writes its own byte range of the files.  The only collectives are
+    the all_gather of the per-rank triangle counts and two barriers around the payload writes (rank 0 opens the files and
+    marks them incomplete before, and gives them their final length and header after).  All ranks must see the same
+    file system (one node).  Returns dict(counts, first, total, stats)."""
+    from .evaluator import WRITE_BEGIN, WRITE_END, write_range
+    n, st = slab.export_slab(cfg_txt, rank, world)
+    if world > 1:
+        mine = torch.tensor([n], dtype=torch.int64)
+        # counts travel on the host: 8 bytes per rank, and gloo / RCCL both take a CPU or a device tensor of their own kind
+        backend = dist.get_backend(group)
+        if backend == "nccl":
+            mine = mine.cuda()
+        counts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(counts, mine, group=group)
+        counts = [int(c.item()) for c in counts]
+    else:
+        counts = [n]
+    first, total = sum(counts[:rank]), sum(counts)
+    paths = [p for p in (stl_path, ply_path) if p is not None]
+    if rank == 0:
+        for p in paths:
+            write_range(p, None, 0, total, WRITE_BEGIN)
+    if world > 1:
+        dist.barrier(group=group)
+    slab.write_slab(stl_path, ply_path, first, total)
+    if world > 1:
+        dist.barrier(group=group)
+    if rank == 0:
+        for p in paths:
+            write_range(p, None, 0, total, WRITE_END)
+    return dict(counts=counts, first=first, total=total, stats=st)
+
+
+def read_stl_triangles(path):
+    """Triangles of a binary STL written by the export ((x, z, y) on disk, utils.hpp:41-103) as a (T,3,3) float32 array."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    n = int(raw[80:84].view("<u4")[0])
+    rec = raw[84:84 + 50 * n].reshape(n, 50)[:, 12:48].copy().view("<f4").reshape(n, 3, 3)
+    return np.ascontiguousarray(rec[:, :, [0, 2, 1]])
+
+
+def read_ply_triangles(path):
+    """Triangles of the reference-layout PLY (un-indexed doubles + uchar/uint faces, utils.hpp:106-154): (T,3,3) float64
+    and the (T,3) face indices."""
+    raw = open(path, "rb").read()
+    end = raw.index(b"end_header\n") + len(b"end_header\n")
+    head = raw[:end].decode()
+    nv = int(head.split("element vertex ")[1].split("\n")[0])
+    nf = int(head.split("element face ")[1].split("\n")[0])
+    v = np.frombuffer(raw, dtype="<f8", count=3 * nv, offset=end).reshape(-1, 3, 3)
+    f = np.frombuffer(raw, dtype=np.uint8, count=13 * nf, offset=end + 24 * nv).reshape(nf, 13)
+    assert len(raw) == end + 24 * nv + 13 * nf and (f[:, 0] == 3).all()
+    return v, f[:, 1:].copy().view("<u4").reshape(nf, 3)

@@ -191,6 +191,17 @@ int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* 
 int dcsg_export(dcsg_ctx* ctx, const char* export_config_txt, const char* stl_path, const char* ply_path,
                 unsigned flags, dcsg_export_stats* stats);
 
+/* Sharded export: Z slab `rank` of `world` equal slabs (world divides 2^gridLevel), stages A ..
+ * projection, no files.  The rank owns the octree nodes whose lowest lattice plane lies in its slab; it evaluates every
+ * lattice value its nodes read itself (including the plane shared with the slab above), so no exchange is needed here.
+ * One context per GPU: one process per GPU over torch.distributed (designcsg_amd/sharded.py), or one host thread per
+ * context in a single process.  The union of the slabs' triangles is the triangle set of dcsg_export. */
+int dcsg_export_slab(dcsg_ctx* ctx, const char* export_config_txt, int rank, int world, unsigned flags,
+                     dcsg_export_stats* stats);
+/* The context's triangles into stl_path / ply_path (either may be NULL) as triangles [first, first + own count) of a
+ * file of `total` triangles, through the range writers above (flags: DCSG_WRITE_BEGIN / DCSG_WRITE_END). */
+int dcsg_write_slab(dcsg_ctx* ctx, const char* stl_path, const char* ply_path, uint64_t first, uint64_t total, unsigned flags);
+
 /* Device time in ms of the most recent lattice sweep (HIP events on its stream; synchronises). */
 int dcsg_last_sweep_ms(dcsg_ctx* ctx, double* ms);
 

@@ -58,12 +58,46 @@ class OracleCheckerBackend:
         return torch.from_numpy(self.scene.gradient_descent(self._tris, steps))
 
 
+class OracleCheckerSlab:
+    """Checker for sharded_export_files: the slab's triangles come from the oracle (those whose centroid lies in the
+    rank's Z range), the files are written by the PRODUCT's range writers (host code of libdcsg_hip, no GPU needed) --
+    the offsets, the BEGIN / END protocol and the barriers of the driver are what this exercises."""
+
+    def __init__(self, scene_dir, table):
+        self.scene, self.table, self.tris = O.Scene.from_dir(scene_dir), table, None
+
+    def export_slab(self, cfg_txt, rank, world):
+        cfg = O.parse_export_config(cfg_txt)
+        c, d, _ = self.scene.estimate_bounding_box(cfg.bounding_box_half_diameter)
+        res = 1 << cfg.grid_level
+        tris, st = self.scene.get_surface(c, d[0], cfg, self.table)
+        z = tris[:, :, 2].astype(np.float64).mean(axis=1)
+        z_of = lambda i: float(O.lattice_point(c, d[0], res, 0, 0, i)[2])
+        lo, hi = rank * res // world, (rank + 1) * res // world
+        keep = (z >= z_of(lo)) & ((z < z_of(hi)) | (rank == world - 1))
+        self.tris = self.scene.gradient_descent(tris[keep], cfg.gradient_descent_steps)
+        return len(self.tris), st
+
+    def write_slab(self, stl_path, ply_path, first, total):
+        from designcsg_amd.evaluator import write_range
+        for path in (stl_path, ply_path):
+            if path is not None:
+                write_range(path, self.tris, first, total, 0)
+
+
 def main():
     out_dir, scene_dir = sys.argv[1], sys.argv[2]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     table = O.LookupTable(open(os.path.join(ROOT, "designcsg_amd", "data", "lookupTable.txt")).read())
     cfg_txt = "10.0\n4\n6\n7\n0.7853981633974483\n5\n16\n512\n4096\n"
+    if os.environ.get("MODE") == "files":
+        res = sharded.sharded_export_files(OracleCheckerSlab(scene_dir, table), cfg_txt, rank, world,
+                                           os.path.join(out_dir, "o.stl"), os.path.join(out_dir, "o.ply"))
+        json.dump({"rank": rank, "counts": res["counts"], "first": res["first"], "total": res["total"]},
+                  open(os.path.join(out_dir, "r%d.json" % rank), "w"))
+        dist.destroy_process_group()
+        return
     from oracle.oracle import parse_export_config
     cfg = parse_export_config(cfg_txt)
     backend = OracleCheckerBackend(scene_dir, table)

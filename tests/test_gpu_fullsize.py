@@ -150,3 +150,43 @@ def test_sharded_driver_single_rank_equals_export(ev):
     want = tri_set_hash(ev.download_triangles())
     res = sharded_export(HipBackend(ev, "cuda:0"), parse_export_config(cfg_txt), 0, 1)
     assert res["counts"] == [st.triangles] and tri_set_hash(res["triangles"]) == want
+
+
+@pytest.mark.parametrize("name,levels,world", [("design2", (6, 8, 9), 4), ("design2", (7, 9, 10), 8), ("flat256", (6, 8, 9), 2),
+                                               ("sphere", (5, 7, 9), 8), ("design2", (2, 5, 6), 8)])
+def test_slab_exports_write_the_whole_mesh_into_one_file(ev, name, levels, world, tmp_path):
+    """dcsg_export_slab + dcsg_write_slab, the entry points every rank of a sharded export calls (here: the ranks one
+    after the other on this GPU): node-wise sweep restricted to the slab, per-rank byte ranges of one .stl / .ply.
+    The files hold exactly the single-GPU export's triangles (as a set; slab order on disk), the per-level statistics
+    add up, and each rank sweeps only its share of the lattice.  (2,5,6) with 8 ranks: the sweep level (2) is coarser
+    than the slabs, so the ranks fall back to dense slab sweeps.)"""
+    from designcsg_amd.evaluator import WRITE_BEGIN, WRITE_END, write_range
+    from designcsg_amd.sharded import read_ply_triangles, read_stl_triangles
+    s = read_scene(name)
+    assert ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
+    cfg_txt = export_config_text(name, levels=list(levels), gd=6)
+    whole = ev.export(cfg_txt, str(tmp_path / "w.stl"), str(tmp_path / "w.ply"))
+    want = tri_set_hash(ev.download_triangles())
+    stats = [ev.export_slab(cfg_txt, r, world) for r in range(world)]
+    counts = [int(st.triangles) for st in stats]
+    assert sum(counts) == whole.triangles
+    for f in ("culled", "subdivided", "leaves", "triangles"):
+        assert [sum(int(getattr(st.mesh, f)[l]) for st in stats) for l in range(16)] == [int(v) for v in getattr(whole.mesh, f)], f
+    if whole.swept_nodes and (1 << max(levels[0], 2)) >= world:
+        assert sum(int(st.swept_nodes) for st in stats) == whole.swept_nodes
+        assert max(int(st.swept_points) for st in stats) < whole.swept_points
+    stl, ply = str(tmp_path / "s.stl"), str(tmp_path / "s.ply")
+    total = sum(counts)
+    for path in (stl, ply):
+        write_range(path, None, 0, total, WRITE_BEGIN)
+    for r in reversed(range(world)):           # any order: every rank owns its byte range
+        ev.export_slab(cfg_txt, r, world)
+        ev.write_slab(stl, ply, sum(counts[:r]), total)
+    for path in (stl, ply):
+        write_range(path, None, 0, total, WRITE_END)
+    assert os.path.getsize(stl) == os.path.getsize(tmp_path / "w.stl") and os.path.getsize(ply) == os.path.getsize(tmp_path / "w.ply")
+    tris = read_stl_triangles(stl)
+    assert tri_set_hash(tris) == want == tri_set_hash(read_stl_triangles(tmp_path / "w.stl"))
+    pv, pf = read_ply_triangles(ply)
+    assert np.array_equal(pv.astype(np.float32).view(np.uint32), tris.view(np.uint32))
+    assert np.array_equal(pf, np.arange(3 * total, dtype=np.uint32).reshape(-1, 3))
