@@ -158,35 +158,31 @@ def secondary_sweeps(scene_dir, device, center, diameter, res):
     return out
 
 
-def export_wall_clock(ev):
-    """Second half of BASELINE.json's metric: export wall-clock seconds, scene files on disk -> .stl and .ply closed
-    (dcsg_export), for Design2 at 512^3 and 1024^3 (BASELINE configs 3 and 4) on this one GPU.  Outside the timed
-    region of the headline number; best of three, the first of which creates the files."""
-    import tempfile
+def export_wall_clock(ev=None):
+    """Second half of BASELINE.json's metric: export wall-clock seconds, scene files on disk -> .stl and .ply closed, for
+    Design2 at 512^3 and 1024^3 (BASELINE configs 3 and 4) on this one GPU, as SURVEY.md 8(d) defines it: each figure comes
+    from a FRESH child process (tools/export_from_disk.py) that creates the context, loads the scene from its files and
+    exports -- once with the JIT cache warm and once with DCSG_JIT_NO_CACHE=1 (the brush text compiled from scratch).
+    Outside the timed region of the headline number."""
+    import subprocess
     d = os.path.join(ROOT, "tests", "golden", "scenes", "design2")
-    status, log = ev.build_from_dir(d)
-    if status != 0:
-        return {"error": log[-400:]}
-    lines = open(os.path.join(d, "exportConfig.txt")).read().split("\n")
     out = []
-    with tempfile.TemporaryDirectory() as tmp:
-        for levels in ((6, 8, 9), (7, 9, 10)):
-            lines[1:4] = [str(v) for v in levels]
-            best = None
-            for _ in range(3):
-                t0 = time.perf_counter()
-                st = ev.export("\n".join(lines), os.path.join(tmp, "o.stl"), os.path.join(tmp, "o.ply"))
-                wall = time.perf_counter() - t0
-                if best is None or wall < best[0]:
-                    best = (wall, st)
-            wall, st = best
-            out.append({"config": "Design2 levels %d/%d/%d (%d^3 voxels)" % (levels + (1 << levels[2],)),
-                        "seconds": round(wall, 4), "triangles": int(st.triangles),
-                        "stl_bytes": os.path.getsize(os.path.join(tmp, "o.stl")),
-                        "ply_bytes": os.path.getsize(os.path.join(tmp, "o.ply")),
-                        "stage_ms": {k: round(getattr(st, "t_" + k) * 1e3, 2)
-                                     for k in ("bbox", "sweep", "mesh", "project", "download", "write_stl", "write_ply")},
-                        "lattice_points_evaluated": int(st.swept_points), "lattice_points": int(st.lattice_points)})
+    for levels in ((6, 8, 9), (7, 9, 10)):
+        entry = {"config": "Design2 levels %d/%d/%d (%d^3 voxels)" % (levels + (1 << levels[2],))}
+        for key, extra in (("warm_jit_cache", []), ("cold_jit", ["--cold-jit"])):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "export_from_disk.py"), "--scene-dir", d, "--levels"]
+                               + [str(v) for v in levels] + extra, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                entry[key] = {"error": (r.stdout + r.stderr)[-400:]}
+                continue
+            j = json.loads(r.stdout.strip().split("\n")[-1])
+            entry.setdefault("triangles", j["triangles"])
+            entry.setdefault("stl_bytes", j["stl_bytes"])
+            entry.setdefault("ply_bytes", j["ply_bytes"])
+            entry[key] = {k: j[k] for k in ("disk_to_files_s", "with_context_s", "create_context_s", "read_files_and_load_scene_s",
+                                            "first_export_s", "steady_export_s", "load_scene_ms")}
+        entry["seconds"] = entry.get("warm_jit_cache", {}).get("disk_to_files_s")
+        out.append(entry)
     return out
 
 
@@ -431,7 +427,7 @@ def main():
         if world == 1 and not args.no_secondary:
             out["secondary_sweeps"] = secondary_sweeps(scene_dir, local_rank, center, diameter, res)
         if world == 1 and not args.no_export:
-            out["export_wall_clock"] = export_wall_clock(ev)
+            out["export_wall_clock"] = export_wall_clock()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_dir, center, diameter, res)
         print(json.dumps(out))

@@ -1,8 +1,8 @@
 """Builds every native artefact of designcsg_amd for gfx950, in-tree under designcsg_amd/_build/.
 
   dcsg_builtin.hsaco        kernels.hip with the HIP-native built-in brush bank (code object)
-  dcsg_kernels_extern.bc    kernels.hip as device bitcode, linked against a scene.cl at load time
-  dcsg_kernels_relaxed.bc   the same with the opt-in relaxed arithmetic (dcsg_set_numerics)
+  dcsg_kernels_{spec,interp}.bc          kernels.hip as device bitcode, linked against a scene.cl at load time
+  dcsg_kernels_relaxed_{spec,interp}.bc  the same with the opt-in relaxed arithmetic (dcsg_set_numerics)
   libdcsg_hip.so            the C ABI (include/dcsg.h): host side + comgr JIT
   jitcache/*.hsaco          per-scene code objects compiled ahead of time (optional warm-up)
 
@@ -62,19 +62,27 @@ def build(verbose=False, prebuild_scenes=True):
     hsaco = os.path.join(OUT, "dcsg_builtin.hsaco")
     if _newer(hsaco, dev_deps):
         _run([HIPCC] + DEVICE_FLAGS + ["--no-gpu-bundle-output", "-c", kernels, "-o", hsaco])
-    bc = os.path.join(OUT, "dcsg_kernels_extern.bc")
-    if _newer(bc, dev_deps):
-        _run([HIPCC] + DEVICE_FLAGS + ["-fgpu-rdc", "-emit-llvm", "-DDCSG_EXTERN_BANK", "-c", kernels, "-o", bc])
+    # Device bitcode linked against a scene's brush text at load time (csrc/jit.cpp), in two kernel sets so that a cold
+    # JIT compiles only what the scene runs: "spec" (per-scene specialised kernels + mesher) and "interp" (the
+    # interpreters + mesher + preview); each also with the opt-in relaxed arithmetic (dcsg_set_numerics).
+    rebuilt = False
+    relaxed_flags = [f for f in DEVICE_FLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast"]
+    for name, flags, defs in (("dcsg_kernels_spec.bc", DEVICE_FLAGS, ["-DDCSG_SET_SPEC"]),
+                              ("dcsg_kernels_interp.bc", DEVICE_FLAGS, ["-DDCSG_SET_INTERP"]),
+                              ("dcsg_kernels_relaxed_spec.bc", relaxed_flags, ["-DDCSG_SET_SPEC", "-DDCSG_RELAXED"]),
+                              ("dcsg_kernels_relaxed_interp.bc", relaxed_flags, ["-DDCSG_SET_INTERP", "-DDCSG_RELAXED"])):
+        bc = os.path.join(OUT, name)
+        if _newer(bc, dev_deps):
+            _run([HIPCC] + flags + ["-fgpu-rdc", "-emit-llvm", "-DDCSG_EXTERN_BANK"] + defs + ["-c", kernels, "-o", bc])
+            rebuilt = True
+    if rebuilt:
         # every cached scene module was linked against the old kernel bitcode (its hash is part of the key):
         # drop them so that stale code objects do not pile up (the fixture scenes are rebuilt below)
         for f in glob.glob(os.path.join(OUT, "jitcache", "*.hsaco")):
             os.remove(f)
-
-    # opt-in relaxed numerics (dcsg_set_numerics): same kernels, FMA contraction allowed, DCSG_RELAXED arithmetic
-    bcr = os.path.join(OUT, "dcsg_kernels_relaxed.bc")
-    if _newer(bcr, dev_deps):
-        flags = [f for f in DEVICE_FLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast"]
-        _run([HIPCC] + flags + ["-fgpu-rdc", "-emit-llvm", "-DDCSG_EXTERN_BANK", "-DDCSG_RELAXED", "-c", kernels, "-o", bcr])
+    for stale in ("dcsg_kernels_extern.bc", "dcsg_kernels_relaxed.bc"):
+        if os.path.exists(os.path.join(OUT, stale)):
+            os.remove(os.path.join(OUT, stale))
 
     _embed_cl()
     host_src = [os.path.join(CSRC, f) for f in ("dcsg_api.cpp", "scene.cpp", "jit.cpp", "specialise.cpp")]

@@ -80,9 +80,25 @@ struct dcsg_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_sweep_time = false;
     std::string err;
+    std::string profile_create, profile_load;  // host-side timing breakdown of dcsg_create / the last dcsg_load_scene
 };
 
 namespace {
+
+// "name=ms;" entries appended to a profile string
+struct Lap {
+    std::string& out;
+    double t;
+    explicit Lap(std::string& o) : out(o), t(now_s()) {}
+    void mark(const char* name)
+    {
+        double n = now_s();
+        char buf[96];
+        snprintf(buf, sizeof(buf), "%s=%.3f;", name, (n - t) * 1e3);
+        out += buf;
+        t = n;
+    }
+};
 
 int fail(dcsg_ctx* c, int code, const std::string& msg)
 {
@@ -130,10 +146,13 @@ void release(DevBuf& b)
     b.cap = 0;
 }
 
-int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
+// kind: 0 the stand-alone module (interpreters + culling kernels), 1 a scene module of the "spec" set (per-scene
+// specialised kernels only), 2 a scene module of the "interp" set (interpreters) -- designcsg_amd/build.py
+int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind)
 {
     static const char* suffix[4] = {"", "_s4", "_s8", "_sp"};
-    for (int v = 0; v < (scene_module ? 4 : 3); v++) {
+    k = Kernels();
+    for (int v = (kind == 1 ? 3 : 0); v < (kind == 1 ? 4 : 3); v++) {
         struct {
             const char* name;
             hipFunction_t* f;
@@ -151,14 +170,13 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, bool scene_module)
                {"dcsg_dedup_count", &k.dd_count},      {"dcsg_dedup_gather", &k.dd_gather},
                {"dcsg_dedup_scatter", &k.dd_scatter}};
     for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
-    if (!scene_module) {
+    if (kind == 0) {
         HIPCHK(c, hipModuleGetFunction(&k.sweep[4], mod, "dcsg_sweep_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.sweep_nodes[4], mod, "dcsg_sweep_nodes_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.bbox[4], mod, "dcsg_bbox_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.project[4], mod, "dcsg_project_c4"));
         k.eval_points[4] = k.eval_points[1];  // arbitrary points have no spatial coherence to exploit
-    }
-    if (scene_module) {
+    } else {
         HIPCHK(c, hipModuleGetFunction(&k.set_ad, mod, "dcsg_set_arbitrary_data"));
     }
     return 0;
@@ -233,7 +251,7 @@ bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std:
     for (int k = 0; k < s.n_stack_prog; k++) n_evals += (s.stack_prog[4 * k] <= 35 || (s.stack_prog[4 * k] >= 41 && s.stack_prog[4 * k] <= 43)) ? 1 : 0;
     const char* env_spec = getenv("DCSG_SPECIALISE");  // max object evaluations to specialise; 0 disables
     int spec_limit = env_spec ? atoi(env_spec) : 48;
-    p.specialise = s.n_stack_prog > 0 && n_evals <= spec_limit;
+    p.specialise = s.n_stack_prog > 0 && n_evals <= spec_limit && !getenv("DCSG_FORCE_VARIANT");  // A/B runs of the interpreters
     p.needs_jit = !(builtin_only && !p.specialise) || relaxed;  // the relaxed arithmetic exists as a scene module only
     if (p.needs_jit) {
         if (builtin_only) p.cl = builtin_scene_cl();
@@ -364,6 +382,7 @@ int dcsg_create(dcsg_ctx** out, int device_id)
     if (device_id < 0 || device_id >= n) return fail(nullptr, DCSG_ERR_INVALID, "device_id out of range");
     dcsg_ctx* c = new dcsg_ctx();
     c->device = device_id;
+    Lap lap(c->profile_create);
     auto bail = [&](int code) {
         g_create_error = c->err;
         dcsg_destroy(c);
@@ -382,6 +401,7 @@ int dcsg_create(dcsg_ctx** out, int device_id)
     CK(hipGetDeviceProperties(&prop, device_id));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
+    lap.mark("hip_runtime_and_device");
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreate(&c->ev0));
     CK(hipEventCreate(&c->ev1));
@@ -390,8 +410,11 @@ int dcsg_create(dcsg_ctx** out, int device_id)
         c->err = "cannot read " + dir + "/dcsg_builtin.hsaco (run __graft_entry__.build())";
         return bail(DCSG_ERR_IO);
     }
+    lap.mark("stream_events_read_code_object");
     CK(hipModuleLoadData(&c->builtin_mod, bytes.data()));
-    if (load_kernels(c, c->builtin_mod, c->kb, false)) return bail(DCSG_ERR_HIP);
+    lap.mark("module_load_builtin");
+    if (load_kernels(c, c->builtin_mod, c->kb, 0)) return bail(DCSG_ERR_HIP);
+    lap.mark("kernel_lookup");
     std::string table_txt;
     if (!read_file(dir + "/../data/lookupTable.txt", table_txt)) {
         c->err = "cannot read packaged lookupTable.txt next to the library";
@@ -404,6 +427,7 @@ int dcsg_create(dcsg_ctx** out, int device_id)
         return bail(r);
     }
     c->ad_host.assign(DCSG_ARBITRARY_DATA_POINTS, 0.0f);
+    lap.mark("lookup_table");
     return 0;
 #undef CK
 }
@@ -505,27 +529,35 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     if (!c) return DCSG_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     c->scene_loaded = false;
+    c->profile_load.clear();
+    Lap lap(c->profile_load);
     Scene s;
     std::string err;
     if (!parse_scene(scene_txt, bp_txt, s, err)) return fail(c, DCSG_ERR_INVALID, err);
+    lap.mark("parse_and_optimise");
     ModulePlan plan;
     if (!plan_scene_module(s, scene_cl, plan, err, c->numerics == DCSG_NUMERICS_RELAXED)) return fail(c, DCSG_ERR_INVALID, err);
+    lap.mark("plan_and_specialise");
     if (!plan.needs_jit) {
         build_blob(s, true);
         c->k = &c->kb;
         c->jit = false;
     } else {
         std::string hsaco, log;
-        if (!jit_scene_module(plan.cl, plan.extra, hsaco, log, nullptr, plan.relaxed))
+        bool cached = false;
+        if (!jit_scene_module(plan.cl, plan.extra, hsaco, log, &cached, plan.relaxed, plan.specialise))
             return fail(c, DCSG_ERR_BUILD, "Error when building evaluation program:\n" + log);
+        lap.mark(cached ? "code_object_from_cache" : "code_object_compiled");
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->scene_mod) {
             HIPCHK(c, hipModuleUnload(c->scene_mod));
             c->scene_mod = nullptr;
         }
         HIPCHK(c, hipModuleLoadData(&c->scene_mod, hsaco.data()));
-        int r = load_kernels(c, c->scene_mod, c->ks, true);
+        lap.mark("module_load_scene");
+        int r = load_kernels(c, c->scene_mod, c->ks, plan.specialise ? 1 : 2);
         if (r) return r;
+        lap.mark("kernel_lookup");
         build_blob(s, plan.null0);
         c->k = &c->ks;
         c->jit = true;
@@ -567,7 +599,16 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
         c->preview_fn = nullptr;
     }
     std::fill(c->ad_host.begin(), c->ad_host.end(), 0.0f);
-    return dcsg_set_arbitrary_data(c, ad, ad ? n_ad : 0);
+    lap.mark("tables_upload");
+    r = dcsg_set_arbitrary_data(c, ad, ad ? n_ad : 0);
+    lap.mark("arbitrary_data_upload");
+    return r;
+}
+
+const char* dcsg_load_profile(const dcsg_ctx* c, int which)
+{
+    if (!c) return "";
+    return which == 0 ? c->profile_create.c_str() : c->profile_load.c_str();
 }
 
 int dcsg_set_numerics(dcsg_ctx* c, int mode)
@@ -1314,7 +1355,7 @@ int dcsg_jit_prebuild_scene_numerics(const char* scene_txt, const char* bp_txt, 
     if (!parse_scene(scene_txt, bp_txt, s, err) || !plan_scene_module(s, scene_cl, plan, err, numerics == DCSG_NUMERICS_RELAXED)) {
         log = err;
         rc = DCSG_ERR_INVALID;
-    } else if (plan.needs_jit && !jit_scene_module(plan.cl, plan.extra, hsaco, log, &cached, plan.relaxed)) {
+    } else if (plan.needs_jit && !jit_scene_module(plan.cl, plan.extra, hsaco, log, &cached, plan.relaxed, plan.specialise)) {
         rc = DCSG_ERR_BUILD;
     }
     if (from_cache) *from_cache = cached ? 1 : 0;

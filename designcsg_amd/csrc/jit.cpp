@@ -266,11 +266,11 @@ static bool run_action(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, 
 }
 
 bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, std::string& hsaco, std::string& log,
-                      bool* from_cache, bool relaxed)
+                      bool* from_cache, bool relaxed, bool spec_set)
 {
     if (from_cache) *from_cache = false;
     std::string kernels_bc;
-    std::string bc_path = library_dir() + (relaxed ? "/dcsg_kernels_relaxed.bc" : "/dcsg_kernels_extern.bc");
+    std::string bc_path = library_dir() + (relaxed ? "/dcsg_kernels_relaxed_" : "/dcsg_kernels_") + (spec_set ? "spec.bc" : "interp.bc");
     if (!read_file(bc_path, kernels_bc)) {
         log = "cannot read " + bc_path + " (run __graft_entry__.build())";
         return false;
@@ -345,7 +345,7 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
                     bc.s, log))
         return false;
     // 2. + the HIP kernels' bitcode
-    if (!add_data(bc.s, AMD_COMGR_DATA_KIND_BC, "dcsg_kernels_extern.bc", kernels_bc)) {
+    if (!add_data(bc.s, AMD_COMGR_DATA_KIND_BC, "dcsg_kernels.bc", kernels_bc)) {
         log = "comgr: cannot add kernel bitcode";
         return false;
     }

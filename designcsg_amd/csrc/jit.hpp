@@ -11,6 +11,7 @@ bool read_file(const std::string& path, std::string& out);
 // extra_cl: generated OpenCL C appended after the epilogue (csrc/specialise.cpp).
 // relaxed: the opt-in relaxed-numerics module (kernels.hip built with DCSG_RELAXED: hardware sqrt / rsq, FMA
 // contraction, no IEEE division sequences) instead of the bit-exact one.
+// spec_set: link the lean kernel set of a specialised scene (the _sp kernels + mesher) instead of the interpreters'.
 bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, std::string& hsaco, std::string& log,
-                      bool* from_cache, bool relaxed = false);
+                      bool* from_cache, bool relaxed = false, bool spec_set = false);
 }  // namespace dcsg

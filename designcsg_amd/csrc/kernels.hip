@@ -126,6 +126,7 @@ __device__ __forceinline__ float dcsg_bank(float x, float y, float z, int shape_
 // OpenCL C next to the brush text -- object constants as literals, one variable per stack level and
 // stencil point -- for 7 points (elements 0..6 of the float8s) and for 1 point.  Same arithmetic in the same
 // order as the interpreters, so the results are bit-identical; no decode, no tables, no LDS.
+#ifndef DCSG_SET_INTERP
 typedef float dcsg_cl_float8 __attribute__((ext_vector_type(8)));
 extern "C" __device__ dcsg_cl_float8 dcsg_spec_eval7(dcsg_cl_float8 px, dcsg_cl_float8 py, dcsg_cl_float8 pz);
 extern "C" __device__ float dcsg_spec_eval1(float x, float y, float z);
@@ -133,6 +134,7 @@ extern "C" __device__ float dcsg_spec_eval1(float x, float y, float z);
 // leave out terms with a zero coefficient, which is exact for finite coordinates only -- specialise.cpp)
 extern "C" __device__ float dcsg_spec_eval1x(float x, float y, float z);
 #define DCSG_HAVE_SPEC 1
+#endif
 #else
 // OpenCL max(gentype x, gentype y): y if x < y, otherwise x
 __device__ __forceinline__ float cl_max_f(float x, float y) { return x < y ? y : x; }
@@ -1075,9 +1077,11 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
     DCSG_SWEEP_KERNEL(NAME, K, 0)                                                                                   \
     DCSG_SWEEP_KERNEL(NAME##_d, K, 1)                                                                               \
     DCSG_SWEEP_KERNEL(NAME##_f, K, 3)
+#ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_SWEEP_KERNELS(dcsg_sweep, 0)
 DCSG_SWEEP_KERNELS(dcsg_sweep_s4, 4)
 DCSG_SWEEP_KERNELS(dcsg_sweep_s8, 8)
+#endif
 #ifdef DCSG_HAVE_SPEC
 DCSG_SWEEP_KERNELS(dcsg_sweep_sp, -1)
 #endif
@@ -1209,9 +1213,11 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
         dcsg_sweep_nodes_body<K>(blob, n_vec4, L, nodes, n_nodes, shift, level, sdf_out, nrm_out, node_mask, hdx,    \
                                  hdy, hdz);                                                                          \
     }
+#ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes, 0)
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_s4, 4)
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_s8, 8)
+#endif
 #ifdef DCSG_HAVE_SPEC
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_sp, -1)
 
@@ -1260,9 +1266,11 @@ __device__ __forceinline__ void dcsg_eval_points_body(const uint4* __restrict__ 
     {                                                                                                               \
         dcsg_eval_points_body<K>(blob, n_vec4, xyz, n, mode, out);                                                  \
     }
+#ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_EVAL_KERNEL(dcsg_eval_points, 0)
 DCSG_EVAL_KERNEL(dcsg_eval_points_s4, 4)
 DCSG_EVAL_KERNEL(dcsg_eval_points_s8, 8)
+#endif
 #ifdef DCSG_HAVE_SPEC
 DCSG_EVAL_KERNEL(dcsg_eval_points_sp, -1)
 #endif
@@ -1355,9 +1363,11 @@ __device__ __forceinline__ void dcsg_bbox_body(const uint4* __restrict__ blob, i
     {                                                                                                               \
         dcsg_bbox_body<K>(blob, n_vec4, cd, half_neg, bb_eps, result);                                              \
     }
+#ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_BBOX_KERNEL(dcsg_bbox, 0)
 DCSG_BBOX_KERNEL(dcsg_bbox_s4, 4)
 DCSG_BBOX_KERNEL(dcsg_bbox_s8, 8)
+#endif
 #ifdef DCSG_HAVE_SPEC
 DCSG_BBOX_KERNEL(dcsg_bbox_sp, -1)
 #endif
@@ -1766,9 +1776,11 @@ __device__ __forceinline__ void dcsg_project_body(const uint4* __restrict__ blob
     {                                                                                                               \
         dcsg_project_body<K>(blob, n_vec4, verts, n_verts, steps);                                                  \
     }
+#ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_PROJECT_KERNEL(dcsg_project, 0)
 DCSG_PROJECT_KERNEL(dcsg_project_s4, 4)
 DCSG_PROJECT_KERNEL(dcsg_project_s8, 8)
+#endif
 #ifdef DCSG_HAVE_SPEC
 DCSG_PROJECT_KERNEL(dcsg_project_sp, -1)
 #endif
@@ -2128,7 +2140,7 @@ dcsg_test_sqrt(const float* __restrict__ in, float* __restrict__ out, unsigned i
     for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < n; i += gridDim.x * DCSG_BLOCK) out[i] = dcsg_sqrt(in[i]);
 }
 
-#ifdef DCSG_EXTERN_BANK
+#if defined(DCSG_EXTERN_BANK) && !defined(DCSG_SET_SPEC)
 // ---------------------------------------------------------------------------
 // Preview: kernel k1 (k1.cl:479-578) -- sphere tracing of the scene plus the three axis markers into a 640 x 480
 // RGB image, one thread per pixel, the build procedure through the generic interpreter.  Scene modules only (the

@@ -91,6 +91,11 @@ class Evaluator:
                 break
         return self.build(rd("scene.txt"), rd("buildprocedure.txt"), scl, ad)
 
+    def load_profile(self):
+        """Host-side milliseconds of dcsg_create and of the last dcsg_load_scene, by stage."""
+        parse = lambda b: {k: float(v) for k, v in (e.split("=") for e in b.decode().split(";") if e)}
+        return {"create": parse(self._L.dcsg_load_profile(self._h, 0)), "load_scene": parse(self._L.dcsg_load_profile(self._h, 1))}
+
     def scene_info(self):
         v = [C.c_int() for _ in range(6)]
         self._ck(self._L.dcsg_scene_info(self._h, *[C.byref(x) for x in v]))

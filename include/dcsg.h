@@ -202,6 +202,10 @@ int dcsg_export_slab(dcsg_ctx* ctx, const char* export_config_txt, int rank, int
  * file of `total` triangles, through the range writers above (flags: DCSG_WRITE_BEGIN / DCSG_WRITE_END). */
 int dcsg_write_slab(dcsg_ctx* ctx, const char* stl_path, const char* ply_path, uint64_t first, uint64_t total, unsigned flags);
 
+/* Diagnostic: host-side timing breakdown, "stage=milliseconds;..." -- which = 0: dcsg_create of this context,
+ * 1: its last dcsg_load_scene.  The string lives until the next load / destroy. */
+const char* dcsg_load_profile(const dcsg_ctx* ctx, int which);
+
 /* Device time in ms of the most recent lattice sweep (HIP events on its stream; synchronises). */
 int dcsg_last_sweep_ms(dcsg_ctx* ctx, double* ms);
 
