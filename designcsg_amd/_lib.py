@@ -18,6 +18,7 @@ EXPORT_SPARSE_NORMALS = 2
 EXPORT_INDEXED_PLY = 4     # opt-in writers beyond the reference's, include/dcsg.h
 EXPORT_STL_NORMALS = 8
 EXPORT_DENSE_SWEEP = 16
+EXPORT_RETOPO = 32        # opt-in intended-semantics retopologize between mesher and projection
 
 
 class ExportConfig(C.Structure):
@@ -69,6 +70,8 @@ PROTOTYPES = {
     "dcsg_mesh_lattice_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.POINTER(ExportConfig),
                                            C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_uint64), C.POINTER(MeshStats), C.c_void_p]),
+    "dcsg_retopologize": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "dcsg_upload_triangles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "dcsg_project_triangles": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "dcsg_project_vertices_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "dcsg_triangles_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),

@@ -41,6 +41,7 @@ struct Kernels {
     hipFunction_t sweep_d[4] = {}, sweep_f[4] = {};  // sweep[v] with the outputs fixed at compile time: SDF only / SDF + normals
     hipFunction_t sweep_nodes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // node-wise sweep per variant
     hipFunction_t dd_insert = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
+    hipFunction_t rt_mark = nullptr, rt_count = nullptr, rt_emit = nullptr;  // opt-in retopologize
 };
 
 double now_s()
@@ -72,7 +73,7 @@ struct dcsg_ctx {
     std::vector<float> ad_host;
     std::vector<uint8_t> tri_table;
     DevBuf d_blob, d_ad, d_tri_table, d_pts, d_out, d_nodes[2], d_info, d_block_sums, d_small, d_tris, d_lat_sdf,
-        d_lat_nrm, d_dd_table, d_dd_rep, d_dd_slot, d_dd_compact;
+        d_lat_nrm, d_dd_table, d_dd_rep, d_dd_slot, d_dd_compact, d_rt_keep, d_rt_out;
     uint64_t n_tris = 0;
     uint64_t last_unique_vertices = 0;  // distinct positions projected by the last dcsg_project_triangles
     void* h_pinned = nullptr;  // host staging for triangle downloads
@@ -168,7 +169,8 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind)
     } tab[] = {{"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan}, {"dcsg_mesh_emit", &k.emit},
                {"dcsg_test_sqrt", &k.test_sqrt},       {"dcsg_dedup_insert", &k.dd_insert},
                {"dcsg_dedup_count", &k.dd_count},      {"dcsg_dedup_gather", &k.dd_gather},
-               {"dcsg_dedup_scatter", &k.dd_scatter}};
+               {"dcsg_dedup_scatter", &k.dd_scatter},  {"dcsg_retopo_mark", &k.rt_mark},
+               {"dcsg_retopo_count", &k.rt_count},     {"dcsg_retopo_emit", &k.rt_emit}};
     for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
     if (kind == 0) {
         HIPCHK(c, hipModuleGetFunction(&k.sweep[4], mod, "dcsg_sweep_c4"));
@@ -439,7 +441,8 @@ void dcsg_destroy(dcsg_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_blob,  &c->d_ad,         &c->d_tri_table, &c->d_pts,  &c->d_out,     &c->d_nodes[0],
                       &c->d_nodes[1], &c->d_info,    &c->d_block_sums, &c->d_small, &c->d_tris, &c->d_lat_sdf,
-                      &c->d_lat_nrm, &c->d_dd_table, &c->d_dd_rep, &c->d_dd_slot, &c->d_dd_compact, &c->d_node_mask};
+                      &c->d_lat_nrm, &c->d_dd_table, &c->d_dd_rep, &c->d_dd_slot, &c->d_dd_compact, &c->d_node_mask,
+                      &c->d_rt_keep, &c->d_rt_out};
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->scene_mod) hipModuleUnload(c->scene_mod);
@@ -1004,11 +1007,96 @@ int dcsg_project_triangles(dcsg_ctx* c, int steps, void* stream)
     return 0;
 }
 
+// Opt-in: T-junction repair in the spirit of cms::retopologize (mesh.hpp:432-529; kernels.hip, oracle_retopologize) on
+// the context's triangle buffer: mesh vertices that lie on a triangle's edges become vertices of its polygon.
+int dcsg_retopologize(dcsg_ctx* c, const float center[3], float diameter, int min_level, int grid_level, void* stream)
+{
+    int r = need_scene(c);
+    if (r) return r;
+    if (!center || grid_level < 1 || grid_level > 12 || min_level < 0 || min_level > grid_level || grid_level - min_level > 5)
+        return fail(c, DCSG_ERR_INVALID, "retopologize needs 0 <= gridLevel - minimumOctreeLevel <= 5 and gridLevel <= 12");
+    if (c->n_tris == 0) return 0;
+    if (c->n_tris * 3 > (1ull << 30)) return fail(c, DCSG_ERR_INVALID, "too many vertices for the cell set");
+    hipStream_t s = (hipStream_t)stream;
+    DcsgRetopo R;
+    for (int k = 0; k < 3; k++) {
+        R.c[k] = center[k];
+        R.hd[k] = diameter / 2.0f;  // DesignCSG.cpp:718
+    }
+    R.grid_points = (float)((1 << grid_level) + 1);
+    R.points_along_edge = 1 << (grid_level - min_level);
+    {   // joinDistance, mesh.hpp:445: double products narrowed to float arguments of min3, then 0.25 * in double
+        float m = (float)(2.0 * R.hd[0] / R.grid_points);
+        for (int k = 1; k < 3; k++) {
+            float v = (float)(2.0 * R.hd[k] / R.grid_points);
+            if (v < m) m = v;
+        }
+        volatile float jd = (float)(0.25 * m);
+        R.join_distance2 = jd * jd;
+    }
+    const unsigned n_tris = (unsigned)c->n_tris, n_verts = n_tris * 3u, n_blocks = (n_tris + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    uint64_t cap = 64;
+    while (cap < 2ull * n_verts) cap <<= 1;
+    unsigned mask = (unsigned)(cap - 1);
+    if ((r = ensure(c, c->d_dd_table, (size_t)cap * 12))) return r;  // keys, then occupants; shares the de-duplication table
+    if ((r = ensure(c, c->d_rt_keep, (size_t)n_tris * 3 * 4))) return r;
+    if ((r = ensure(c, c->d_block_sums, (size_t)n_blocks * 2 * sizeof(unsigned)))) return r;
+    if ((r = ensure(c, c->d_small, 4096))) return r;
+    unsigned long long* keys = (unsigned long long*)c->d_dd_table.p;
+    unsigned* rep = (unsigned*)((char*)c->d_dd_table.p + (size_t)cap * 8);
+    HIPCHK(c, hipMemsetAsync(keys, 0, (size_t)cap * 8, s));
+    HIPCHK(c, hipMemsetAsync(rep, 0xff, (size_t)cap * 4, s));
+    const float* tris = (const float*)c->d_tris.p;
+    unsigned* keep = (unsigned*)c->d_rt_keep.p;
+    unsigned* bs = (unsigned*)c->d_block_sums.p;
+    unsigned* totals = (unsigned*)c->d_small.p;
+    {
+        void* args[] = {(void*)&tris, (void*)&n_verts, &R, (void*)&keys, (void*)&rep, &mask};
+        if ((r = launch(c, c->k->rt_mark, sweep_grid(c, (n_verts + DCSG_BLOCK - 1) / DCSG_BLOCK), DCSG_BLOCK, 0, s, args))) return r;
+    }
+    {
+        void* args[] = {(void*)&tris, (void*)&n_tris, &R, (void*)&keys, (void*)&rep, &mask, (void*)&keep, (void*)&bs};
+        if ((r = launch(c, c->k->rt_count, n_blocks, DCSG_BLOCK, 0, s, args))) return r;
+    }
+    {
+        void* args[] = {(void*)&bs, (void*)&n_blocks, (void*)&totals};
+        if ((r = launch(c, c->k->scan, 1, 1024, 0, s, args))) return r;
+    }
+    unsigned tot[2];
+    HIPCHK(c, hipMemcpyAsync(tot, totals, sizeof(tot), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const unsigned n_out = tot[0];
+    if ((r = ensure(c, c->d_rt_out, (size_t)(n_out ? n_out : 1) * 9 * sizeof(float)))) return r;
+    float* out = (float*)c->d_rt_out.p;
+    {
+        void* args[] = {(void*)&tris, (void*)&n_tris, &R, (void*)&keys, (void*)&rep, &mask, (void*)&keep, (void*)&bs, (void*)&out};
+        if ((r = launch(c, c->k->rt_emit, n_blocks, DCSG_BLOCK, 0, s, args))) return r;
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    std::swap(c->d_tris, c->d_rt_out);
+    c->n_tris = n_out;
+    return 0;
+}
+
 int dcsg_triangles_device(dcsg_ctx* c, const float** d_triangles, uint64_t* n)
 {
     if (!c) return DCSG_ERR_INVALID;
     if (d_triangles) *d_triangles = (const float*)c->d_tris.p;
     if (n) *n = c->n_tris;
+    return 0;
+}
+
+// Replaces the context's triangle buffer with caller-provided triangles (9 floats each, host memory): lets the
+// post-meshing stages (retopologize, projection, writers) run on any mesh.
+int dcsg_upload_triangles(dcsg_ctx* c, const float* tris, uint64_t n)
+{
+    if (!c || (n && !tris)) return DCSG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int r = ensure(c, c->d_tris, (size_t)(n ? n : 1) * 9 * sizeof(float));
+    if (r) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n) HIPCHK(c, hipMemcpy(c->d_tris.p, tris, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice));
+    c->n_tris = n;
     return 0;
 }
 
@@ -1485,6 +1573,10 @@ int export_mesh_stage(dcsg_ctx* c, const dcsg_export_config& cfg, int rank, int 
                                           z_own_hi, &n_tris, &st.mesh, c->stream)))
             return r;
         st.t_mesh = now_s() - t0;
+    }
+    if (flags & DCSG_EXPORT_RETOPO) {  // opt-in; the default reproduces the reference's (repaired) identity
+        if ((r = dcsg_retopologize(c, st.box_center, diameter, cfg.min_level, cfg.grid_level, c->stream))) return r;
+        n_tris = c->n_tris;
     }
     st.triangles = n_tris;
 

@@ -35,6 +35,13 @@ struct DcsgMeshParams {
     int mask_level, mask_shift;
 };
 
+struct DcsgRetopo {  // T-junction repair in the spirit of cms::retopologize (mesh.hpp:432-529; oracle_retopologize)
+    float c[3], hd[3];   // bounds.center, bounds.halfDiameter
+    float grid_points;   // (float)((1 << gridLevel) + 1)
+    int points_along_edge;  // 1 << (gridLevel - minimumOctreeLevel), <= 32
+    float join_distance2;   // joinDistance^2, joinDistance = 0.25 * min_k(2 hd_k / grid_points) (mesh.hpp:445)
+};
+
 struct DcsgCamera {  // kernel k1's campos / right / up / forward buffers (k1.cl:481-486)
     float o[3], r[3], u[3], f[3];
 };

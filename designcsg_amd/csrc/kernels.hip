@@ -2133,6 +2133,215 @@ dcsg_dedup_scatter(float* __restrict__ verts, const unsigned int* __restrict__ r
     }
 }
 
+// ---------------------------------------------------------------------------
+// Opt-in: T-junction repair in the spirit of cms::retopologize (mesh.hpp:432-529).  The reference's function is
+// undefined behaviour and unfinished; oracle/dcsg_oracle.c (oracle_retopologize) defines the semantics these kernels
+// are held to, bit for bit: every cell (Indexer, mesh.hpp:413-421) remembers the mesh vertex of lowest index inside
+// it; every triangle samples P points along each of its edges, and the occupant of a sample's cell joins the
+// triangle's polygon when it is not an end of the edge, lies within joinDistance of the sample and was not accepted
+// just before; the polygon is triangulated by the strip rule (geometry.hpp:228-248).  n polygon points give n - 2
+// triangles; a triangle with nothing on its edges is reproduced as it is.  Three passes: mark (hash map insert,
+// atomicMin of the vertex index), count (per-triangle accept masks + block sums for the scan), emit.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long dcsg_retopo_key(const DcsgRetopo& R, float x, float y, float z)
+{
+    const float v[3] = {x, y, z};
+    unsigned long long key = 0ull;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float f = ((v[k] - R.c[k]) + R.hd[k]) / R.hd[k];  // diff, sum, termQuotient (mesh.hpp:415)
+        f = f * R.grid_points;                            // scaled (:417)
+        int i = (int)f;                                   // Vector3i(float, float, float) (:418)
+        key = (key << 21) | (unsigned long long)((unsigned int)i & 0x1fffffu);
+    }
+    return key + 1ull;  // 0 marks an empty slot
+}
+__device__ __forceinline__ unsigned int dcsg_retopo_hash(unsigned long long k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    return (unsigned int)k;
+}
+
+// rep[] must be preset to 0xffffffff, keys[] to 0
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_retopo_mark(const float* __restrict__ verts, unsigned int n_verts, DcsgRetopo R, unsigned long long* __restrict__ keys,
+                 unsigned int* __restrict__ rep, unsigned int mask)
+{
+    for (unsigned int v = blockIdx.x * DCSG_BLOCK + threadIdx.x; v < n_verts; v += gridDim.x * DCSG_BLOCK) {
+        unsigned long long key = dcsg_retopo_key(R, verts[(size_t)v * 3], verts[(size_t)v * 3 + 1], verts[(size_t)v * 3 + 2]);
+        unsigned int h = dcsg_retopo_hash(key) & mask;
+        for (;;) {
+            unsigned long long old = atomicCAS(&keys[h], 0ull, key);
+            if (old == 0ull || old == key) break;
+            h = (h + 1u) & mask;
+        }
+        atomicMin(&rep[h], v);  // the occupant is the vertex of lowest index: independent of the insertion order
+    }
+}
+
+// occupant of the cell with this key, or 0xffffffff
+__device__ __forceinline__ unsigned int dcsg_retopo_occupant(const unsigned long long* __restrict__ keys,
+                                                             const unsigned int* __restrict__ rep, unsigned int mask,
+                                                             unsigned long long key)
+{
+    unsigned int h = dcsg_retopo_hash(key) & mask;
+    for (;;) {
+        unsigned long long t = keys[h];
+        if (t == key) return rep[h];
+        if (t == 0ull) return 0xffffffffu;
+        h = (h + 1u) & mask;
+    }
+}
+// sample i of the edge a -> b (mesh.hpp:502-505): start + delta * ((float)i / pointsAlongEdge)
+__device__ __forceinline__ void dcsg_retopo_sample(const float* a, const float* b, int i, int P, float q[3])
+{
+    float f = (float)i / (float)P;
+    q[0] = a[0] + (b[0] - a[0]) * f;
+    q[1] = a[1] + (b[1] - a[1]) * f;
+    q[2] = a[2] + (b[2] - a[2]) * f;
+}
+__device__ __forceinline__ bool dcsg_same_bits3(const float* a, const float* b)
+{
+    return dcsg_same_bits(a[0], b[0]) && dcsg_same_bits(a[1], b[1]) && dcsg_same_bits(a[2], b[2]);
+}
+// the vertex that joins the polygon at sample i of edge a -> b, or 0xffffffff (`last`: the one accepted before it)
+__device__ __forceinline__ unsigned int dcsg_retopo_joined(const float* __restrict__ verts, const DcsgRetopo& R,
+                                                           const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ rep,
+                                                           unsigned int mask, const float* a, const float* b, int i, unsigned int last)
+{
+    float q[3];
+    dcsg_retopo_sample(a, b, i, R.points_along_edge, q);
+    unsigned int r = dcsg_retopo_occupant(keys, rep, mask, dcsg_retopo_key(R, q[0], q[1], q[2]));
+    if (r == 0xffffffffu || r == last) return 0xffffffffu;
+    const float V[3] = {verts[(size_t)r * 3], verts[(size_t)r * 3 + 1], verts[(size_t)r * 3 + 2]};
+    float ux = V[0] - q[0], uy = V[1] - q[1], uz = V[2] - q[2];
+    if (dcsg_same_bits3(V, a) || dcsg_same_bits3(V, b) || !(ux * ux + uy * uy + uz * uz <= R.join_distance2)) return 0xffffffffu;
+    return r;
+}
+
+// accept[3*t + e]: bit i set = the occupant of sample i's cell joins edge e of triangle t (bit 0: the start vertex).
+// block_sums[2*b] = output triangles of block b.
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_retopo_count(const float* __restrict__ tris, unsigned int n_tris, DcsgRetopo R, const unsigned long long* __restrict__ keys,
+                  const unsigned int* __restrict__ rep, unsigned int mask, unsigned int* __restrict__ accept,
+                  unsigned int* __restrict__ block_sums)
+{
+    unsigned int t = blockIdx.x * DCSG_BLOCK + threadIdx.x;
+    unsigned int n_out = 0;
+    if (t < n_tris) {
+        float T[9];
+        for (int k = 0; k < 9; k++) T[k] = tris[(size_t)t * 9 + k];
+        unsigned int n = 0;
+        for (int e = 0; e < 3; e++) {
+            const float* a = T + 3 * e;
+            const float* b = T + 3 * ((e + 1) % 3);
+            unsigned int m = 1u, last = 0xffffffffu;
+            for (int i = 1; i < R.points_along_edge; i++) {
+                unsigned int r = dcsg_retopo_joined(tris, R, keys, rep, mask, a, b, i, last);
+                if (r != 0xffffffffu) {
+                    m |= 1u << i;
+                    last = r;
+                }
+            }
+            accept[(size_t)t * 3 + e] = m;
+            n += (unsigned int)__popc(m);
+        }
+        n_out = n - 2;  // the strip rule yields n - 2 triangles (n >= 3)
+    }
+    unsigned int w = wave_sum(n_out);
+    __shared__ unsigned int part[DCSG_BLOCK / DCSG_WAVE];
+    if ((threadIdx.x & (DCSG_WAVE - 1)) == 0) part[threadIdx.x / DCSG_WAVE] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int s = 0;
+        for (int k = 0; k < DCSG_BLOCK / DCSG_WAVE; k++) s += part[k];
+        block_sums[2 * blockIdx.x] = s;
+        block_sums[2 * blockIdx.x + 1] = 0;
+    }
+}
+
+// point number k (0-based, edge order then sample order) of triangle T's polygon
+__device__ __forceinline__ void dcsg_retopo_point(const float* __restrict__ verts, const DcsgRetopo& R,
+                                                  const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ rep,
+                                                  unsigned int mask, const float T[9], const unsigned int m[3], int k, float q[3])
+{
+    int e = 0;
+    int c0 = __popc(m[0]), c1 = __popc(m[1]);
+    if (k >= c0 + c1) {
+        e = 2;
+        k -= c0 + c1;
+    } else if (k >= c0) {
+        e = 1;
+        k -= c0;
+    }
+    unsigned int mm = e == 0 ? m[0] : (e == 1 ? m[1] : m[2]);
+    for (int j = 0; j < k; j++) mm &= mm - 1u;  // drop the k lowest set bits
+    int i = __ffs((int)mm) - 1;
+    const float* a = T + 3 * e;
+    const float* b = T + 3 * ((e + 1) % 3);
+    if (i == 0) {
+        q[0] = a[0], q[1] = a[1], q[2] = a[2];
+        return;
+    }
+    // the occupant of sample i's cell (it was accepted in the count pass: no test needed again)
+    float s[3];
+    dcsg_retopo_sample(a, b, i, R.points_along_edge, s);
+    unsigned int r = dcsg_retopo_occupant(keys, rep, mask, dcsg_retopo_key(R, s[0], s[1], s[2]));
+    q[0] = verts[(size_t)r * 3], q[1] = verts[(size_t)r * 3 + 1], q[2] = verts[(size_t)r * 3 + 2];
+}
+
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_retopo_emit(const float* __restrict__ tris, unsigned int n_tris, DcsgRetopo R, const unsigned long long* __restrict__ keys,
+                 const unsigned int* __restrict__ rep, unsigned int mask, const unsigned int* __restrict__ accept,
+                 const unsigned int* __restrict__ block_base, float* __restrict__ out)
+{
+    __shared__ unsigned int wsum[DCSG_BLOCK / DCSG_WAVE];
+    unsigned int t = blockIdx.x * DCSG_BLOCK + threadIdx.x;
+    unsigned int m[3] = {0u, 0u, 0u};
+    int n = 0;
+    if (t < n_tris) {
+        for (int e = 0; e < 3; e++) {
+            m[e] = accept[(size_t)t * 3 + e];
+            n += __popc(m[e]);
+        }
+    }
+    unsigned int n_out = n >= 3 ? (unsigned int)(n - 2) : 0u;
+    unsigned int inc = wave_scan_incl(n_out);
+    const int lane = threadIdx.x & (DCSG_WAVE - 1), wave = threadIdx.x / DCSG_WAVE;
+    if (lane == DCSG_WAVE - 1) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int off = block_base[2 * blockIdx.x] + inc - n_out;
+    for (int k = 0; k < wave; k++) off += wsum[k];
+    if (n_out == 0) return;
+    float T[9];
+    for (int k = 0; k < 9; k++) T[k] = tris[(size_t)t * 9 + k];
+    // getIndexTriangleStrip (geometry.hpp:228-248) over the loop 0 .. n-1
+    auto emit = [&](int a, int b, int c) {
+        float* o = out + (size_t)off * 9;
+        float q[3];
+        dcsg_retopo_point(tris, R, keys, rep, mask, T, m, a, q);
+        o[0] = q[0], o[1] = q[1], o[2] = q[2];
+        dcsg_retopo_point(tris, R, keys, rep, mask, T, m, b, q);
+        o[3] = q[0], o[4] = q[1], o[5] = q[2];
+        dcsg_retopo_point(tris, R, keys, rep, mask, T, m, c, q);
+        o[6] = q[0], o[7] = q[1], o[8] = q[2];
+        off++;
+    };
+    int start = 0;
+    if (n & 1) {
+        emit(0, 1, n - 1);
+        start = 1;  // pop_front
+    }
+    const int len = n - start;
+    for (int A = 0; A < len / 2 - 1; A++) {
+        int B = A + 1, D = len - 1 - A, C = D - 1;
+        emit(start + A, start + B, start + C);
+        emit(start + C, start + D, start + A);
+    }
+}
+
 // Diagnostic: dcsg_sqrt over an array (exhaustive test of the custom square root).
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_test_sqrt(const float* __restrict__ in, float* __restrict__ out, unsigned int n)

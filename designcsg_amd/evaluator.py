@@ -198,13 +198,24 @@ class Evaluator:
                                              out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def retopologize(self, center, diameter, min_level, grid_level, stream=0):
+        """Opt-in: cms::retopologize as intended (T-junction vertices join the polygons of the triangles whose edges
+        they lie on) on the context's triangles.  Returns the new triangle count."""
+        self._ck(self._L.dcsg_retopologize(self._h, _f3(center), diameter, min_level, grid_level, C.c_void_p(stream or None)))
+        return self.triangles_device()[1]
+
+    def upload_triangles(self, tris):
+        t = np.ascontiguousarray(tris, dtype=np.float32)
+        self._ck(self._L.dcsg_upload_triangles(self._h, _fptr(t) if t.size else None, t.size // 9))
+
     def export(self, export_config_txt, stl_path=None, ply_path=None, dense_normals=False, indexed_ply=False,
-               stl_normals=False, dense_sweep=False):
+               stl_normals=False, dense_sweep=False, retopologize=False):
         """MyFrame::OnExportInner end to end on this GPU.  indexed_ply / stl_normals select the opt-in writers
         (shared vertices; real facet normals) instead of the reference's file layouts."""
         st = ExportStats()
         flags = (_lib.EXPORT_DENSE_NORMALS if dense_normals else 0) | (_lib.EXPORT_INDEXED_PLY if indexed_ply else 0) | \
-            (_lib.EXPORT_STL_NORMALS if stl_normals else 0) | (_lib.EXPORT_DENSE_SWEEP if dense_sweep else 0)
+            (_lib.EXPORT_STL_NORMALS if stl_normals else 0) | (_lib.EXPORT_DENSE_SWEEP if dense_sweep else 0) | \
+            (_lib.EXPORT_RETOPO if retopologize else 0)
         self._ck(self._L.dcsg_export(self._h, export_config_txt.encode(),
                                      None if stl_path is None else os.fsencode(stl_path),
                                      None if ply_path is None else os.fsencode(ply_path), flags, C.byref(st)))

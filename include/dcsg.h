@@ -142,6 +142,17 @@ int dcsg_set_lookup_table(dcsg_ctx* ctx, const char* lookup_table_txt);
 int dcsg_mesh_lattice_device(dcsg_ctx* ctx, const float center[3], float diameter, const dcsg_export_config* cfg,
                              const float* d_sdf, const float* d_normals, int z_lo, int z_hi, int z_own_lo,
                              int z_own_hi, uint64_t* n_triangles, dcsg_mesh_stats* stats, void* stream);
+/* Opt-in: T-junction repair in the spirit of cms::retopologize (mesh.hpp:432-529) on the context's triangle buffer.
+ * The reference's own function cannot be a specification: it is undefined behaviour (by-value parameters captured by
+ * reference, :414,:424; it segfaults), termQuotient multiplies (geometry.hpp:71-73), and its de-duplication helper
+ * (:445-462) is computed and never used; with only the captures repaired it is the identity on the reference's designs,
+ * which is what the default export reproduces.  This stage does what the function is evidently for, built from its own
+ * ingredients (cells of Indexer, P = 2^(grid - min) samples per edge, joinDistance, the strip rule): a mesh vertex of
+ * another triangle lying on an edge becomes a vertex of this triangle's polygon.  Semantics defined by
+ * oracle_retopologize (oracle/dcsg_oracle.c), parity unpinned by construction.  gridLevel - minimumOctreeLevel <= 5. */
+int dcsg_retopologize(dcsg_ctx* ctx, const float center[3], float diameter, int min_level, int grid_level, void* stream);
+/* Replace the context's triangles with caller-provided ones (host memory, 9 floats each). */
+int dcsg_upload_triangles(dcsg_ctx* ctx, const float* triangles, uint64_t n_triangles);
 /* cms::performGradientDescent (mesh.hpp:531-593) on the context's triangle buffer, in place. */
 int dcsg_project_triangles(dcsg_ctx* ctx, int steps, void* stream);
 /* Same on caller-owned device vertices (n_vertices x 3 floats). */
@@ -188,6 +199,7 @@ int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* 
 #define DCSG_EXPORT_DENSE_SWEEP 16u   /* sweep the whole lattice even where the node-wise sweep would do */
 #define DCSG_EXPORT_INDEXED_PLY 4u    /* ply_path gets dcsg_write_ply_indexed instead of the reference layout */
 #define DCSG_EXPORT_STL_NORMALS 8u    /* stl_path gets dcsg_write_stl_normals instead of zero normals */
+#define DCSG_EXPORT_RETOPO 32u        /* run dcsg_retopologize between the mesher and the projection (default: identity) */
 int dcsg_export(dcsg_ctx* ctx, const char* export_config_txt, const char* stl_path, const char* ply_path,
                 unsigned flags, dcsg_export_stats* stats);
 

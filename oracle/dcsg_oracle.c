@@ -851,6 +851,132 @@ void oracle_gradient_descent(const oracle_scene *s, int steps, float *tris, size
     }
 }
 
+/* ------------------------------------------------------------------ */
+/* T-junction repair in the spirit of cms::retopologize (mesh.hpp:432-529) -- PARITY UNPINNED, OWN DEFINITION.
+ *
+ * The reference's function cannot serve as a specification.  As written it is undefined behaviour (Indexer / Deindexer
+ * return lambdas that capture by-value parameters by reference, :414,:424: it segfaults under g++) and
+ * Vector3f::termQuotient multiplies (geometry.hpp:71-73).  With only the captures repaired it is the identity on the
+ * reference's designs (SURVEY a-9) because the mis-scaled cells are far smaller than the sample spacing; with the
+ * quotient repaired as well it pushes every edge sample that falls into the start vertex's own cell into the polygon
+ * (measured: sphere 4/6/7 33 608 -> 169 608 triangles, all new ones slivers) -- its de-duplication helper
+ * (joinDistance, Vector3fIsInVector, :447-462) is computed and never used.  The function is unfinished.
+ *
+ * What it is evidently FOR -- a vertex of a finer neighbour lying on a triangle's edge (a T-junction) should become a
+ * vertex of that triangle -- is defined here from its own ingredients, and the HIP kernels are held to THIS:
+ *   cell(v)      = (int3)( ((v - center) + hd) / hd * (float)(2^grid + 1) )           Indexer, quotient as named
+ *   occupant(c)  = the mesh vertex of lowest index in the soup that lies in cell c    (occupied map, :489-494)
+ *   joinDistance = 0.25 * min over axes of 2 hd / (2^grid + 1)                        (:445)
+ *   per triangle, per edge a -> b, for i = 1 .. P-1, P = 2^(grid - min) (:496-505): q = a + (b - a) * ((float)i / P);
+ *       V = occupant(cell(q)); V joins the polygon after a (in order of i) when it is neither a nor b, lies within
+ *       joinDistance of q, and is not the vertex accepted just before it on this edge
+ *   polygon = A, [joined on AB], B, [joined on BC], C, [joined on CA]; triangulated by getIndexTriangleStrip
+ *       (geometry.hpp:228-248) as the reference does (:515-523)
+ * The inserted points are MESH VERTICES (not sample points), so the repaired triangle shares its sub-edges with its
+ * neighbours exactly; a triangle with nothing on its edges is reproduced bit for bit.  The default export does not run
+ * this stage (it reproduces the reference, whose repaired function is the identity): DCSG_EXPORT_RETOPO opts in.      */
+typedef struct cell_map {
+    uint64_t *keys; /* 0 = empty; key = 1 + packed cell */
+    uint32_t *rep;  /* lowest vertex index in the cell */
+    size_t mask;
+} cell_map;
+
+static inline uint64_t retopo_cell_key(const float v[3], const float c[3], const float hd[3], float grid_points)
+{
+    uint64_t key = 0;
+    for (int k = 0; k < 3; k++) {
+        float f = ((v[k] - c[k]) + hd[k]) / hd[k]; /* diff, sum, termQuotient */
+        f = f * grid_points;                       /* scaled */
+        int i = (int)f;                            /* Vector3i(float, float, float) */
+        key = (key << 21) | ((uint64_t)(uint32_t)i & 0x1fffffu);
+    }
+    return key + 1;
+}
+static inline size_t cell_hash(uint64_t k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    return (size_t)k;
+}
+static void cell_insert(cell_map *s, uint64_t key, uint32_t vertex)
+{
+    size_t h = cell_hash(key) & s->mask;
+    while (s->keys[h] && s->keys[h] != key) h = (h + 1) & s->mask;
+    if (!s->keys[h] || vertex < s->rep[h]) s->rep[h] = vertex;
+    s->keys[h] = key;
+}
+static int64_t cell_occupant(const cell_map *s, uint64_t key)
+{
+    size_t h = cell_hash(key) & s->mask;
+    while (s->keys[h]) {
+        if (s->keys[h] == key) return (int64_t)s->rep[h];
+        h = (h + 1) & s->mask;
+    }
+    return -1;
+}
+static inline int same_bits3(const float *a, const float *b) { return memcmp(a, b, 12) == 0; }
+
+float oracle_retopo_join_distance(const float half_diameter[3], int grid_level)
+{
+    float gp = (float)((1 << grid_level) + 1);
+    float a = (float)(2.0 * half_diameter[0] / gp), b = (float)(2.0 * half_diameter[1] / gp), c = (float)(2.0 * half_diameter[2] / gp);
+    float m = a;
+    if (b < m) m = b;
+    if (c < m) m = c;
+    return (float)(0.25 * m);
+}
+
+size_t oracle_retopologize(const float *tris, size_t n_tris, const float center[3], const float half_diameter[3],
+                           int min_level, int grid_level, float **out)
+{
+    const float grid_points = (float)((1 << grid_level) + 1);
+    const int P = 1 << (grid_level - min_level);
+    const float jd = oracle_retopo_join_distance(half_diameter, grid_level), jd2 = jd * jd;
+    cell_map map;
+    size_t cap = 64;
+    while (cap < 6 * n_tris + 16) cap <<= 1;
+    map.keys = (uint64_t *)calloc(cap, sizeof(uint64_t));
+    map.rep = (uint32_t *)calloc(cap, sizeof(uint32_t));
+    map.mask = cap - 1;
+    for (size_t v = 0; v < 3 * n_tris; v++) cell_insert(&map, retopo_cell_key(tris + 3 * v, center, half_diameter, grid_points), (uint32_t)v);
+    tri_vec o = {0};
+    float (*ngon)[3] = (float (*)[3])malloc((size_t)(3 * P) * sizeof(*ngon));
+    int *loop = (int *)malloc((size_t)(3 * P) * sizeof(int));
+    int (*st)[3] = (int (*)[3])malloc((size_t)(3 * P + 4) * sizeof(*st));
+    for (size_t t = 0; t < n_tris; t++) {
+        const float *T = tris + 9 * t;
+        int n = 0;
+        for (int e = 0; e < 3; e++) {
+            const float *a = T + 3 * e, *b = T + 3 * ((e + 1) % 3);
+            float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+            memcpy(ngon[n++], a, 12);
+            int64_t last = -1;
+            for (int i = 1; i < P; i++) {
+                float f = (float)i / (float)P;
+                float q[3] = {a[0] + d[0] * f, a[1] + d[1] * f, a[2] + d[2] * f};
+                int64_t r = cell_occupant(&map, retopo_cell_key(q, center, half_diameter, grid_points));
+                if (r < 0 || r == last) continue;
+                const float *V = tris + 3 * r;
+                float ux = V[0] - q[0], uy = V[1] - q[1], uz = V[2] - q[2];
+                if (same_bits3(V, a) || same_bits3(V, b) || !(ux * ux + uy * uy + uz * uz <= jd2)) continue;
+                memcpy(ngon[n++], V, 12);
+                last = r;
+            }
+        }
+        for (int i = 0; i < n; i++) loop[i] = i;
+        int k = triangle_strip(loop, n, st);
+        for (int j = 0; j < k; j++) tri_push(&o, ngon[st[j][0]], ngon[st[j][1]], ngon[st[j][2]]);
+    }
+    free(ngon);
+    free(loop);
+    free(st);
+    free(map.keys);
+    free(map.rep);
+    *out = o.v;
+    return o.n;
+}
+
 void oracle_free(void *p) { free(p); }
 
 /* ------------------------------------------------------------------ */

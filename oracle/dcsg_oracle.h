@@ -92,6 +92,12 @@ size_t oracle_get_surface(const oracle_scene *s, const oracle_box *bb, const ora
                           const int tri_count[256], const int tris[256][5][3],
                           float **out, oracle_mesh_stats *stats, int threads);
 void oracle_gradient_descent(const oracle_scene *s, int steps, float *tris, size_t n_tris, int threads);
+/* T-junction repair in the spirit of cms::retopologize (mesh.hpp:432-529): OWN DEFINITION, PARITY UNPINNED (the
+ * reference's function is undefined behaviour and unfinished; see dcsg_oracle.c).  Returns the triangle count; *out is
+ * malloc'd (oracle_free). */
+float oracle_retopo_join_distance(const float half_diameter[3], int grid_level);
+size_t oracle_retopologize(const float *tris, size_t n_tris, const float center[3], const float half_diameter[3],
+                           int min_level, int grid_level, float **out);
 void oracle_free(void *p);
 
 /* ---- utils.hpp writers ---------------------------------------------- */

@@ -119,6 +119,8 @@ def lib():
                                          C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(MeshStats), C.c_int]
         L.oracle_gradient_descent.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
         L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_retopologize.restype = C.c_size_t
+        L.oracle_retopologize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.oracle_render_preview.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_scene_set_shader.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_write_stl.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
@@ -232,6 +234,20 @@ class Scene:
         tris = np.ascontiguousarray(tris, dtype=np.float32).copy()
         lib().oracle_gradient_descent(self._h, steps, _ptr(tris), tris.shape[0], threads)
         return tris
+
+
+def retopologize(tris, center, diameter, min_level, grid_level):
+    """cms::retopologize as intended (see dcsg_oracle.c: parity unpinned, the reference's is undefined behaviour)."""
+    t = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 3, 3)
+    c = np.ascontiguousarray(center, dtype=np.float32)
+    d = np.ascontiguousarray([diameter] * 3 if np.isscalar(diameter) else diameter, dtype=np.float32)
+    hd = (d / np.float32(2.0)).astype(np.float32)   # DesignCSG.cpp:718
+    out = C.c_void_p()
+    n = lib().oracle_retopologize(_ptr(t), len(t), _ptr(c), _ptr(hd), min_level, grid_level, C.byref(out))
+    arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_float)), shape=(n, 3, 3)).copy() if n else \
+        np.zeros((0, 3, 3), dtype=np.float32)
+    lib().oracle_free(out)
+    return arr
 
 
 def read_arbitrary_data(d):

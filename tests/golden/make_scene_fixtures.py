@@ -40,6 +40,7 @@ DESIGNS = {
     "ad_table": os.path.join(OWN_DESIGNS, "ad_table.py"),
     "prefabs": os.path.join(OWN_DESIGNS, "prefabs.py"),
     "const_table": os.path.join(OWN_DESIGNS, "const_table.py"),
+    "global_state": os.path.join(OWN_DESIGNS, "global_state.py"),
 }
 FILES = ["scene.txt", "buildprocedure.txt", "scene.cl", "exportConfig.txt"]
 

@@ -1,0 +1,172 @@
+
+        
+
+
+        
+
+         
+
+__global int SHAPE_SEL = -1;
+__global float SHAPE_GAIN = 0.0;
+
+float selected_shape(float3 v){
+    float3 a = fabs(v);
+    float g = SHAPE_GAIN;
+    if(SHAPE_SEL==0){
+        return length(v)-0.5*g;
+    }
+    if(SHAPE_SEL==1){
+        return T_max(a.x-0.5*g,T_max(a.y-0.25,a.z-0.5*g));
+    }
+    if(SHAPE_SEL==2){
+        return T_max(length((float2)(v.x,v.z))-0.5*g,a.y-0.5);
+    }
+    return MAX_DISTANCE;
+}
+
+
+        
+        float sd0( float3 v){
+
+            return MAX_DISTANCE;
+
+        }
+        
+
+        float sd1( float3 v){
+
+            return 0.0;
+
+        }
+        
+
+        float sd2( float3 v){
+
+            return length(v)-0.5;
+
+        }
+        
+
+        float sd3( float3 v){
+
+            
+
+    v=fabs(v);
+    float x = length((float2)(v.x,v.z));
+    float y = v.y;
+    return max(x-0.5,y-0.5);
+
+
+
+        }
+        
+
+        float sd4( float3 v){
+
+            
+    v=fabs(v);
+    return max(v.x-0.5,max(v.y-0.5,v.z-0.5));
+
+
+        }
+        
+
+        float sd5( float3 v){
+
+            SHAPE_SEL = 0; SHAPE_GAIN = 0.75; return selected_shape(v);
+
+        }
+        
+
+        float sd6( float3 v){
+
+            SHAPE_SEL = 1; SHAPE_GAIN = 1.0; return selected_shape(v);
+
+        }
+        
+
+        float sd7( float3 v){
+
+            SHAPE_SEL = 2; SHAPE_GAIN = 0.5; return selected_shape(v);
+
+        }
+        
+
+        
+        float3 shader0 (float3 gv, float3 lv, float3 n){
+
+            return fabs(n);
+
+        }
+        
+
+        float3 shader1 (float3 gv, float3 lv, float3 n){
+
+            
+        
+        float3 n_g = n.x*rgt_g+n.y*upp_g+n.z*fwd_g;
+
+        float L = dot(n_g,(float3)(0.0,0.0,-1.0)); return (float3)(L,L,L);
+
+
+
+        
+
+        }
+        
+
+
+        float sdf_bank(float3 v, unsigned char shape_id){
+
+            switch(shape_id){
+
+                
+case 0: return sd0(v); break;
+
+
+case 1: return sd1(v); break;
+
+
+case 2: return sd2(v); break;
+
+
+case 3: return sd3(v); break;
+
+
+case 4: return sd4(v); break;
+
+
+case 5: return sd5(v); break;
+
+
+case 6: return sd6(v); break;
+
+
+case 7: return sd7(v); break;
+
+
+            }
+
+            return 0.0;
+
+        }
+
+        float3 shader_bank(float3 gv, float3 lv, float3 n, unsigned char material_id){
+
+
+            switch(material_id){
+
+                
+case 0: return shader0(gv,lv,n); break;
+
+
+case 1: return shader1(gv,lv,n); break;
+
+
+            }
+
+            return (float3)(1.0, 1.0, 1.0);
+        }
+        
+        
+        
