@@ -87,6 +87,7 @@ PROTOTYPES = {
     "dcsg_parse_export_config": (C.c_int, [C.c_char_p, C.POINTER(ExportConfig)]),
     "dcsg_export": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint, C.POINTER(ExportStats)]),
     "dcsg_export_slab": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_uint, C.POINTER(ExportStats)]),
+    "dcsg_export_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint, C.POINTER(ExportStats)]),
     "dcsg_write_slab": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint]),
     "dcsg_load_profile": (C.c_char_p, [C.c_void_p, C.c_int]),
     "dcsg_last_sweep_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

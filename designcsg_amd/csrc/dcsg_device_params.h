@@ -33,6 +33,7 @@ struct DcsgMeshParams {
     // covering lattice indices [n << mask_shift, (n+1) << mask_shift] per axis.  NULL = the lattice is dense.
     const unsigned char* node_mask;
     int mask_level, mask_shift;
+    int use_spec;  // on-demand samples through the module's per-scene specialised code (spec kernel set only)
 };
 
 struct DcsgRetopo {  // T-junction repair in the spirit of cms::retopologize (mesh.hpp:432-529; oracle_retopologize)

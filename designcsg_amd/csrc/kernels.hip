@@ -1437,6 +1437,14 @@ __device__ __forceinline__ float sample_sdf(const Sampler& S, const float p[3])
         size_t n1 = (size_t)L.res + 1;
         return S.sdf[((size_t)(iz - S.P->z_lo) * n1 + iy) * n1 + ix];
     }
+#ifdef DCSG_HAVE_SPEC
+    if (S.P->use_spec) {  // the module's per-scene code (same bits as the interpreter, a fraction of its instructions)
+        float sd, u0, u1, u2;
+        dcsg_stencil_spec<true>(dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy), dcsg_lattice_coord(L, 2, iz), true, false,
+                                sd, u0, u1, u2);
+        return sd;
+    }
+#endif
     return dcsg_primary_sdf(*S.scene, dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy),
                             dcsg_lattice_coord(L, 2, iz));
 }
@@ -1453,6 +1461,14 @@ __device__ __forceinline__ void sample_normal(const Sampler& S, const float p[3]
         n[2] = q[2];
         return;
     }
+#ifdef DCSG_HAVE_SPEC
+    if (S.P->use_spec) {
+        float sd;
+        dcsg_stencil_spec<true>(dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy), dcsg_lattice_coord(L, 2, iz), false, true,
+                                sd, n[0], n[1], n[2]);
+        return;
+    }
+#endif
     dcsg_get_normal(*S.scene, dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy),
                     dcsg_lattice_coord(L, 2, iz), n[0], n[1], n[2]);
 }

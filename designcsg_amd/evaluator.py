@@ -235,6 +235,19 @@ class Evaluator:
                                          None if ply_path is None else os.fsencode(ply_path), int(first), int(total), int(flags)))
 
 
+def export_multi(evaluators, export_config_txt, stl_path=None, ply_path=None, dense_normals=False):
+    """dcsg_export_multi: the sharded export in ONE process, evaluators[i] (one per GPU, same scene loaded) = Z slab i.
+    Returns the per-slab ExportStats."""
+    n = len(evaluators)
+    hs = (C.c_void_p * n)(*[e._h for e in evaluators])
+    st = (ExportStats * n)()
+    rc = _lib.lib().dcsg_export_multi(hs, n, export_config_txt.encode(), None if stl_path is None else os.fsencode(stl_path),
+                                      None if ply_path is None else os.fsencode(ply_path),
+                                      _lib.EXPORT_DENSE_NORMALS if dense_normals else 0, st)
+    _lib.check(evaluators[0]._h, rc)
+    return list(st)
+
+
 WRITE_BEGIN, WRITE_END = 1, 2
 
 

@@ -214,6 +214,14 @@ int dcsg_export_slab(dcsg_ctx* ctx, const char* export_config_txt, int rank, int
  * file of `total` triangles, through the range writers above (flags: DCSG_WRITE_BEGIN / DCSG_WRITE_END). */
 int dcsg_write_slab(dcsg_ctx* ctx, const char* stl_path, const char* ply_path, uint64_t first, uint64_t total, unsigned flags);
 
+/* The sharded export inside one process: ctxs[i] (one context per GPU, created with dcsg_create(&ctx, device_i) and
+ * with the same scene loaded) runs Z slab i of n on its own host thread; then every thread writes its byte range of
+ * stl_path / ply_path (either may be NULL).  n must divide 2^gridLevel.  stats: n entries (per slab) or NULL.  This is
+ * how a single-process host (the reference's is one: DesignCSG.cpp:638-790) uses several GPUs through this boundary;
+ * the contexts may also share a device (rehearsal). */
+int dcsg_export_multi(dcsg_ctx* const* ctxs, int n, const char* export_config_txt, const char* stl_path, const char* ply_path,
+                      unsigned flags, dcsg_export_stats* stats);
+
 /* Diagnostic: host-side timing breakdown, "stage=milliseconds;..." -- which = 0: dcsg_create of this context,
  * 1: its last dcsg_load_scene.  The string lives until the next load / destroy. */
 const char* dcsg_load_profile(const dcsg_ctx* ctx, int which);

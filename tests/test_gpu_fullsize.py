@@ -190,3 +190,30 @@ def test_slab_exports_write_the_whole_mesh_into_one_file(ev, name, levels, world
     pv, pf = read_ply_triangles(ply)
     assert np.array_equal(pv.astype(np.float32).view(np.uint32), tris.view(np.uint32))
     assert np.array_equal(pf, np.arange(3 * total, dtype=np.uint32).reshape(-1, 3))
+
+
+def test_export_multi_through_the_c_boundary(ev, tmp_path):
+    """dcsg_export_multi: n contexts in one process (here all on this GPU; one per GPU on a node), one host thread and
+    one Z slab each, per-slab byte ranges of the two files.  The files hold the single-context export's triangle set."""
+    from designcsg_amd.evaluator import Evaluator, export_multi
+    from designcsg_amd.sharded import read_ply_triangles, read_stl_triangles
+    s = read_scene("design2")
+    cfg_txt = export_config_text("design2", levels=(6, 8, 9), gd=10)
+    assert ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
+    whole = ev.export(cfg_txt)
+    want = tri_set_hash(ev.download_triangles())
+    evs = [Evaluator(0) for _ in range(4)]
+    try:
+        for e in evs:
+            assert e.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
+        for _ in range(2):   # the second run overwrites the files in place
+            st = export_multi(evs, cfg_txt, tmp_path / "m.stl", tmp_path / "m.ply")
+            assert sum(int(x.triangles) for x in st) == whole.triangles == 395668
+            tris = read_stl_triangles(tmp_path / "m.stl")
+            assert tri_set_hash(tris) == want
+            pv, _ = read_ply_triangles(tmp_path / "m.ply")
+            assert np.array_equal(pv.astype(np.float32).view(np.uint32), tris.view(np.uint32))
+            assert os.path.getsize(tmp_path / "m.stl") == 19783484 and os.path.getsize(tmp_path / "m.ply") == 33632029
+    finally:
+        for e in evs:
+            e.close()
