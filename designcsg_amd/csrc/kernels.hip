@@ -1024,8 +1024,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             iy0 = t0 - iz0 * n1;
             plane0 = iz0 + (unsigned int)z0;                                // ... to here
         }
-#pragma unroll 1
-        for (unsigned int done = 0u; done < DCSG_RUN && done < left; done += DCSG_WAVE, idx0 += DCSG_WAVE) {
+        auto pass = [&](unsigned int done) {
             float x, y, z;
             if (ax) {
                 DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
@@ -1041,7 +1040,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                 y = dcsg_lattice_coord(L, 1, (int)iy);
                 z = dcsg_lattice_coord(L, 2, (int)iz + z0);
             }
-            if (left - done < DCSG_WAVE && lane >= left - done) continue;  // the launch's last wave
+            if (left - done < DCSG_WAVE && lane >= left - done) return;  // the launch's last wave
             float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
             if (K == 0) {
                 if (want_sdf) sd = dcsg_primary_sdf(s, x, y, z);
@@ -1061,6 +1060,16 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                 o[1] = ny;
                 o[2] = nz;
             }
+            idx0 += DCSG_WAVE;
+        };
+        if (K < 0 && MODE == 1 && left >= DCSG_RUN) {
+            // the cheapest kernel (SDF only, per-scene code): four independent passes in flight hide the square root's
+            // latency and quarter the loop overhead
+#pragma unroll
+            for (unsigned int done = 0u; done < DCSG_RUN; done += DCSG_WAVE) pass(done);
+        } else {
+#pragma unroll 1
+            for (unsigned int done = 0u; done < DCSG_RUN && done < left; done += DCSG_WAVE) pass(done);
         }
     }
 }
