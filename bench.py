@@ -213,6 +213,9 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: sphere512 on one GPU (BASELINE config 2), sphere1024 on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--numerics", default=os.environ.get("DCSG_NUMERICS", "exact"), choices=["exact", "relaxed"],
+                    help="exact (default; bit-identical to the reference arithmetic) or the opt-in relaxed module -- a relaxed "
+                         "line says so in config.numerics and is not the headline number")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary sweep lines (LDS-table interpreter, "
                     "relaxed numerics, 1024^3)")
     ap.add_argument("--no-export", action="store_true", help="skip the export wall-clock lines (second half of the metric)")
@@ -252,6 +255,7 @@ def main():
     res = 1 << grid_level
     n1 = res + 1
     ev = Evaluator(local_rank)
+    ev.set_numerics(args.numerics)
     status, log = ev.build_from_dir(scene_dir)
     if status != 0:
         sys.exit("scene build failed:\n" + log)
@@ -397,7 +401,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload,
-                       "grid_level": grid_level,
+                       "grid_level": grid_level, "numerics": args.numerics,
                        "parallelism": ("z-slab x%d: %d stacked %d^3-voxel boxes, boundary plane over RCCL" % (world, world, res)
                                        if weak else "z-slab x%d of one %d^3-voxel lattice, halo plane over RCCL" % (world, res)),
                        "lattice_points": (world * res + 1) * plane if weak else n1 ** 3},

@@ -386,6 +386,7 @@ int dcsg_create(dcsg_ctx** out, int device_id)
     if (device_id < 0 || device_id >= n) return fail(nullptr, DCSG_ERR_INVALID, "device_id out of range");
     dcsg_ctx* c = new dcsg_ctx();
     c->device = device_id;
+    if (const char* e = getenv("DCSG_NUMERICS")) c->numerics = strcmp(e, "relaxed") == 0 ? DCSG_NUMERICS_RELAXED : DCSG_NUMERICS_EXACT;
     Lap lap(c->profile_create);
     auto bail = [&](int code) {
         g_create_error = c->err;
