@@ -1356,7 +1356,7 @@ int write_range(const char* path, const float* tris, uint64_t n, uint64_t first,
     }
     if (ok && n) ok = ply ? ply_payload(fd, tris, n, first, total, reserved) : stl_payload(fd, tris, n, first, reserved);
     if (ok && end) ok = ftruncate(fd, size) == 0 && pwrite_all(fd, (const unsigned char*)header, (size_t)hl, 0);
-    if (!ok) (void)ftruncate(fd, 0);  // nothing that could pass for a finished file stays behind
+    if (!ok && ftruncate(fd, 0) != 0) ok = false;  // nothing that could pass for a finished file stays behind
     return close(fd) == 0 && ok ? 0 : DCSG_ERR_IO;
 }
 

@@ -97,6 +97,44 @@ def test_point_eval_bit_exact(ev, oracle, name, interpreter, monkeypatch):
             assert np.array_equal(np.where(both_nan, 0, bits(got)), np.where(both_nan, 0, bits(want)))
 
 
+@pytest.mark.parametrize("interpreter", ["auto", "stack", "generic"])
+def test_huge_axis_vectors_keep_the_written_out_arithmetic(ev, oracle, interpreter, monkeypatch, tmp_path):
+    """Objects whose reciprocal axis vectors are huge (scales of 1e-4 ... 1e-20): a product of a coefficient and a
+    coordinate difference can overflow, and "+ 0 * dx" then is NaN, not nothing -- the specialiser's constant-aware
+    simplification (zero terms dropped, T_min onto MAX_DISTANCE as v_min) must not be applied to them.  Every device
+    path against the oracle, including coordinates large enough to overflow the transforms."""
+    if interpreter != "auto":
+        monkeypatch.setenv("DCSG_SPECIALISE", "0")
+    if interpreter == "generic":
+        monkeypatch.setenv("DCSG_FORCE_VARIANT", "0")
+    scene_txt = ("0 1 0.000000 0.000000 0.000000 0.200000 0.000000 0.000000 0.000000 0.200000 0.000000 0.000000 0.000000 0.200000\n"
+                 "2 1 0.100000 0.000000 0.000000 30000.000000 0.000000 0.000000 0.000000 0.500000 0.000000 0.000000 0.000000 0.500000\n"
+                 "4 1 0.000000 0.300000 0.000000 0.000000 200000000000000000000.000000 0.000000 2.000000 0.000000 0.000000 0.000000 0.000000 100000000000000000000000000000.000000\n"
+                 "3 1 -0.200000 0.000000 0.100000 0.700000 0.000000 0.000000 0.000000 0.000000 -4000.000000 0.000000 0.900000 0.000000\n")
+    bp = "0 0 0 0\n0 2 1 1\n2 0 1 0\n0 4 2 1\n2 0 1 0\n0 3 3 1\n4 1 -1 1\n3 0 1 0\n1 0 -1 -1"
+    assert ev.build(scene_txt, bp, None)[0] == 0
+    assert ev.scene_info()["interpreter"] == {"auto": 3, "stack": 1, "generic": 0}[interpreter]
+    d = tmp_path / "huge"
+    d.mkdir()
+    (d / "scene.txt").write_text(scene_txt)
+    (d / "buildprocedure.txt").write_text(bp)
+    osc = oracle.Scene.from_dir(str(d))
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.uniform(-2, 2, (20000, 3)), rng.uniform(-1e-3, 1e-3, (20000, 3)) + [0.1, 0.3, 0.1],
+                          rng.uniform(-1, 1, (2000, 3)) * 1e12, rng.uniform(-1, 1, (2000, 3)) * 1e29]).astype(np.float32)
+    pts[:4] = [(0.1, 0.3, 0.0), (0.1, 0.0, 0.0), (-0.2, 0.0, 0.1), (0.0, 0.0, 0.0)]
+    with np.errstate(all="ignore"):
+        for got, want in ((ev.eval_sdf_at_points(pts), osc.eval_sdf(pts)), (ev.eval_normal_at_points(pts), osc.eval_normal(pts))):
+            both_nan = np.isnan(got) & np.isnan(want)
+            assert np.array_equal(np.where(both_nan, 0, bits(got)), np.where(both_nan, 0, bits(want)))
+        c, dia = [0.0, 0.0, 0.0], 4.0
+        gs, gn = ev.eval_lattice(c, dia, 64)
+        ws, wn = osc.eval_lattice(c, dia, 64)
+        for got, want in ((gs, ws), (gn, wn)):
+            both_nan = np.isnan(got) & np.isnan(want)
+            assert np.array_equal(np.where(both_nan, 0, bits(got)), np.where(both_nan, 0, bits(want)))
+
+
 def _camera(yaw, pitch, dist):
     """Orthonormal right / up / forward (float32) and a camera position `dist` behind the origin along forward."""
     cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)

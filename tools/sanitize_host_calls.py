@@ -19,6 +19,10 @@ for d in sorted(glob.glob("/root/repo/tests/golden/scenes/*/")):
             for _ in range(3):
                 i=int(rng.integers(0,len(b))); b[i]=int(rng.choice([ord('9'),ord('-'),ord(' '),ord('x'),ord('\n'),ord('7')]))
         compile(st,bytes(b[:int(rng.integers(0,len(b)+1))])); compile(st[:int(rng.integers(0,len(st)+1))],bytes(b)); n+=2
+# opcodes outside the file format (incl. the host's own fused / stack numbers) with wild operands: dropped, not indexed
+st=open("/root/repo/tests/golden/scenes/mixed_groups/scene.txt","rb").read()
+junk=["0 0 0 0"]+["%d 2 %d %d"%(op,5000+op,(-1)**op*(70000+op)) for op in list(range(9,64))+[-1,255,100000]]+["16 2 0 5000","0 2 1 1","2 0 1 0","1 0 -1 -1"]
+assert compile(st,"\n".join(junk).encode())==0; n+=1
 class Cfg(C.Structure): _fields_=[("a",C.c_float),("b",C.c_int*3),("c",C.c_float),("d",C.c_int*4)]
 L.dcsg_parse_export_config.argtypes=[C.c_char_p,C.c_void_p]
 for t in (b"",b"1\n2",b"10.0\n6\n8\n9\n0.7\n50\n16\n512\n4096\n",b"x\ny\n",b"1e400\n-5\n999999999999\n1\n1\n1\n1\n1\n1"):
@@ -36,6 +40,18 @@ for f,extra in (("dcsg_write_stl",False),("dcsg_write_ply",False),("dcsg_write_s
         t=rng.normal(size=(m,3,3)).astype(np.float32)
         args=[os.path.join(os.path.dirname(os.environ.get("DCSG_ASAN_LIB", "/tmp/dcsg_asan/x")), "o.bin").encode(),t.ctypes.data_as(C.c_void_p),m]+([C.byref(C.c_uint64())] if extra else [])
         assert fn(*args)==0; n+=1
+# byte-range writers: three ranges in shuffled order between BEGIN and END, over a longer stale file
+for f in ("dcsg_write_stl_range","dcsg_write_ply_range"):
+    fn=getattr(L,f); fn.argtypes=[C.c_char_p,C.c_void_p,C.c_uint64,C.c_uint64,C.c_uint64,C.c_uint]
+    path=os.path.join(os.path.dirname(os.environ.get("DCSG_ASAN_LIB", "/tmp/dcsg_asan/x")), "r.bin").encode()
+    open(path,"wb").write(b"z"*9_000_000)
+    t=rng.normal(size=(70000,3,3)).astype(np.float32); cuts=[0,1,30000,70000]
+    assert fn(path,None,0,0,70000,1)==0
+    for k in (2,0,1):
+        part=np.ascontiguousarray(t[cuts[k]:cuts[k+1]])
+        assert fn(path,part.ctypes.data_as(C.c_void_p),len(part),cuts[k],70000,0)==0
+    assert fn(path,None,0,0,70000,2)==0; n+=5
+    assert fn(path,t.ctypes.data_as(C.c_void_p),10,69995,70000,0)!=0
 L.dcsg_angle_q_star.restype=C.c_float; L.dcsg_angle_q_star.argtypes=[C.c_float]
 for v in (0.0,0.785,3.2,-1.0,float("nan")): L.dcsg_angle_q_star(v)
 print("sanitizer run finished:", n, "calls")
