@@ -59,8 +59,8 @@ struct ComgrApi {
 #undef DCSG_COMGR_FN
 };
 
-// Which compiler builds the code objects: the file libamd_comgr would be loaded from, its size and time stamp (a ROCm
-// upgrade changes at least one of them), so that cached code objects of another compiler are never reused.  Only
+// Which compiler builds the code objects: the file libamd_comgr would be loaded from and its size (a ROCm upgrade changes
+// at least one of them; the time stamp is left out: the same image unpacked elsewhere must hit the cache), so that cached code objects of another compiler are never reused.  Only
 // stat(2): a cache hit must not pay for loading the compiler.
 static std::vector<std::string> comgr_candidates()
 {
@@ -77,7 +77,7 @@ static std::string comgr_identity()
     for (auto& c : comgr_candidates()) {
         struct stat st;
         if (stat(c.c_str(), &st) == 0)
-            return c + ":" + std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtime);
+            return c + ":" + std::to_string((long long)st.st_size);
     }
     return "unknown";
 }

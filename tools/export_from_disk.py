@@ -6,7 +6,7 @@
 
 Prints one JSON line: seconds of (1) importing the binding and loading libdcsg_hip, (2) dcsg_create (HIP runtime +
 device + built-in code object), (3) reading the scene files + dcsg_load_scene (parse, code object from the JIT cache, or
-compiled when --cold-jit sets DCSG_JIT_NO_CACHE=1, module load, uploads), (4) the first dcsg_export (creates the output
+compiled when --cold-jit sets DCSG_JIT_NO_CACHE=1 and AMD_COMGR_CACHE=0, module load, uploads), (4) the first dcsg_export (creates the output
 files, first-touch of every buffer) and (5) the best of the following exports (steady state: files overwritten in
 place); plus the library's own stage breakdown of (2) and (3).  `disk_to_files_s` = (3) + (4): what pressing "export" in
 a running host costs the first time; `with_context_s` adds (2).
@@ -31,6 +31,7 @@ def main():
     args = ap.parse_args()
     if args.cold_jit:
         os.environ["DCSG_JIT_NO_CACHE"] = "1"
+        os.environ["AMD_COMGR_CACHE"] = "0"   # libamd_comgr keeps a cache of its own (~/.cache/comgr): cold means cold
     t0 = time.perf_counter()
     from designcsg_amd.evaluator import Evaluator
     from designcsg_amd import _lib
