@@ -42,7 +42,7 @@ struct Kernels {
     hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr;
     hipFunction_t sweep_d[4] = {}, sweep_f[4] = {};  // sweep[v] with the outputs fixed at compile time: SDF only / SDF + normals
     hipFunction_t sweep_nodes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // node-wise sweep per variant
-    hipFunction_t dd_insert = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
+    hipFunction_t dd_insert = nullptr, dd_resolve = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
     hipFunction_t rt_mark = nullptr, rt_count = nullptr, rt_emit = nullptr;  // opt-in retopologize
 };
 
@@ -81,6 +81,8 @@ struct dcsg_ctx {
     void* h_pinned = nullptr;  // host staging for triangle downloads
     size_t h_pinned_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t copy_stream = nullptr;          // downloads that overlap the projection of the next chunk
+    hipEvent_t chunk_ready[8] = {}, chunk_done[8] = {};
     bool have_sweep_time = false;
     std::string err;
     std::string profile_create, profile_load;  // host-side timing breakdown of dcsg_create / the last dcsg_load_scene
@@ -171,7 +173,8 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind)
     } tab[] = {{"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan}, {"dcsg_mesh_emit", &k.emit},
                {"dcsg_test_sqrt", &k.test_sqrt},       {"dcsg_dedup_insert", &k.dd_insert},
                {"dcsg_dedup_count", &k.dd_count},      {"dcsg_dedup_gather", &k.dd_gather},
-               {"dcsg_dedup_scatter", &k.dd_scatter},  {"dcsg_retopo_mark", &k.rt_mark},
+               {"dcsg_dedup_scatter", &k.dd_scatter},  {"dcsg_dedup_resolve", &k.dd_resolve},
+               {"dcsg_retopo_mark", &k.rt_mark},
                {"dcsg_retopo_count", &k.rt_count},     {"dcsg_retopo_emit", &k.rt_emit}};
     for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
     if (kind == 0) {
@@ -410,6 +413,11 @@ int dcsg_create(dcsg_ctx** out, int device_id)
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreate(&c->ev0));
     CK(hipEventCreate(&c->ev1));
+    CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 8; k++) {
+        CK(hipEventCreateWithFlags(&c->chunk_ready[k], hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&c->chunk_done[k], hipEventDisableTiming));
+    }
     std::string dir = library_dir(), bytes;
     if (!read_file(dir + "/dcsg_builtin.hsaco", bytes)) {
         c->err = "cannot read " + dir + "/dcsg_builtin.hsaco (run __graft_entry__.build())";
@@ -453,6 +461,11 @@ void dcsg_destroy(dcsg_ctx* c)
     if (c->builtin_mod) hipModuleUnload(c->builtin_mod);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    for (int k = 0; k < 8; k++) {
+        if (c->chunk_ready[k]) hipEventDestroy(c->chunk_ready[k]);
+        if (c->chunk_done[k]) hipEventDestroy(c->chunk_done[k]);
+    }
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -949,19 +962,21 @@ int dcsg_project_vertices_device(dcsg_ctx* c, float* d_xyz, size_t n_vertices, i
     return launch(c, c->k->project[c->variant], sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), (hipStream_t)stream, args);
 }
 
-// performGradientDescent on the context's triangle buffer.  Copies of one position move identically, so one
-// representative per distinct position is projected (kernels.hip, "Vertex de-duplication") and copied back.
-int dcsg_project_triangles(dcsg_ctx* c, int steps, void* stream)
+}  // extern "C"
+
+namespace {
+// Vertex de-duplication up to the compact list (kernels.hip): owners of distinct positions in buffer order.  After it
+// returns, compact[slot] holds the positions, slot_of / rep map every vertex to its slot, and the scanned per-block owner
+// counts (block_sums[2*b]) give the number of owners before vertex 256 b.  probe_blocks / probe_out: scanned counts to
+// fetch along with the total (chunk boundaries of the pipelined export).
+struct Dedup {
+    unsigned n = 0, n_blocks = 0, n_unique = 0;
+};
+int dedup_prepare(dcsg_ctx* c, hipStream_t s, Dedup& d, const unsigned* probe_blocks = nullptr, unsigned* probe_out = nullptr,
+                  int n_probe = 0)
 {
-    if (!c) return DCSG_ERR_INVALID;
     const size_t n_verts = (size_t)c->n_tris * 3;
-    const char* env = getenv("DCSG_DEDUP");
-    // the hash table has 2^k >= 2 n slots of 32-bit vertex ids: beyond 2^30 vertices the plain projection runs
-    if (steps <= 0 || n_verts < 4096 || n_verts > (1ull << 30) || (env && atoi(env) == 0))
-        return dcsg_project_vertices_device(c, (float*)c->d_tris.p, n_verts, steps, stream);
-    int r = need_scene(c);
-    if (r) return r;
-    hipStream_t s = (hipStream_t)stream;
+    int r;
     unsigned n = (unsigned)n_verts, n_blocks = (n + DCSG_BLOCK - 1) / DCSG_BLOCK;
     uint64_t table_size64 = 1;
     while (table_size64 < 2ull * n) table_size64 <<= 1;  // <= 2^31 for n <= 2^30
@@ -985,6 +1000,10 @@ int dcsg_project_triangles(dcsg_ctx* c, int steps, void* stream)
         if ((r = launch(c, c->k->dd_insert, grid, DCSG_BLOCK, 0, s, args))) return r;
     }
     {
+        void* args[] = {(void*)&table, &n, (void*)&rep};
+        if ((r = launch(c, c->k->dd_resolve, grid, DCSG_BLOCK, 0, s, args))) return r;
+    }
+    {
         void* args[] = {(void*)&rep, &n, (void*)&bs};
         if ((r = launch(c, c->k->dd_count, n_blocks, DCSG_BLOCK, 0, s, args))) return r;
     }
@@ -994,6 +1013,8 @@ int dcsg_project_triangles(dcsg_ctx* c, int steps, void* stream)
     }
     unsigned tot[2];
     HIPCHK(c, hipMemcpyAsync(tot, totals, sizeof(tot), hipMemcpyDeviceToHost, s));
+    for (int k = 0; k < n_probe; k++)
+        HIPCHK(c, hipMemcpyAsync(&probe_out[k], bs + 2 * (size_t)probe_blocks[k], sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     unsigned n_unique = tot[0];
     if ((r = ensure(c, c->d_dd_compact, (size_t)(n_unique ? n_unique : 1) * 3 * sizeof(float)))) return r;
@@ -1002,13 +1023,49 @@ int dcsg_project_triangles(dcsg_ctx* c, int steps, void* stream)
         void* args[] = {(void*)&verts, (void*)&rep, &n, (void*)&bs, (void*)&compact, (void*)&slot};
         if ((r = launch(c, c->k->dd_gather, n_blocks, DCSG_BLOCK, 0, s, args))) return r;
     }
-    if ((r = dcsg_project_vertices_device(c, compact, n_unique, steps, stream))) return r;
-    {
-        void* args[] = {(void*)&verts, (void*)&rep, (void*)&slot, (void*)&compact, &n};
-        if ((r = launch(c, c->k->dd_scatter, grid, DCSG_BLOCK, 0, s, args))) return r;
-    }
+    d.n = n;
+    d.n_blocks = n_blocks;
+    d.n_unique = n_unique;
     c->last_unique_vertices = n_unique;
     return 0;
+}
+
+// every copy in [first, first + count) takes the projected position of its representative
+int dedup_scatter(dcsg_ctx* c, hipStream_t s, unsigned first, unsigned count)
+{
+    if (!count) return 0;
+    float* verts = (float*)c->d_tris.p;
+    unsigned* rep = (unsigned*)c->d_dd_rep.p;
+    unsigned* slot = (unsigned*)c->d_dd_slot.p;
+    float* compact = (float*)c->d_dd_compact.p;
+    void* args[] = {(void*)&verts, (void*)&rep, (void*)&slot, (void*)&compact, &first, &count};
+    return launch(c, c->k->dd_scatter, sweep_grid(c, (count + DCSG_BLOCK - 1) / DCSG_BLOCK), DCSG_BLOCK, 0, s, args);
+}
+
+bool dedup_applies(const dcsg_ctx* c, int steps)
+{
+    const size_t n_verts = (size_t)c->n_tris * 3;
+    const char* env = getenv("DCSG_DEDUP");
+    // the hash table has 2^k >= 2 n slots of 32-bit vertex ids: beyond 2^30 vertices the plain projection runs
+    return !(steps <= 0 || n_verts < 4096 || n_verts > (1ull << 30) || (env && atoi(env) == 0));
+}
+}  // namespace
+
+extern "C" {
+
+// performGradientDescent on the context's triangle buffer.  Copies of one position move identically, so one
+// representative per distinct position is projected (kernels.hip, "Vertex de-duplication") and copied back.
+int dcsg_project_triangles(dcsg_ctx* c, int steps, void* stream)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    if (!dedup_applies(c, steps)) return dcsg_project_vertices_device(c, (float*)c->d_tris.p, (size_t)c->n_tris * 3, steps, stream);
+    int r = need_scene(c);
+    if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    Dedup d;
+    if ((r = dedup_prepare(c, s, d))) return r;
+    if ((r = dcsg_project_vertices_device(c, (float*)c->d_dd_compact.p, d.n_unique, steps, stream))) return r;
+    return dedup_scatter(c, s, 0, d.n);
 }
 
 // Opt-in: T-junction repair in the spirit of cms::retopologize (mesh.hpp:432-529; kernels.hip, oracle_retopologize) on
@@ -1575,7 +1632,8 @@ namespace {
 // plane it shares with the slab above, are evaluated by this rank itself (a sample is a pure function of its lattice
 // index), so this entry point needs no exchange; the RCCL halo exchange of the dense-sweep path lives in
 // designcsg_amd/sharded.py.  Triangles stay in the context's buffer.
-int export_mesh_stage(dcsg_ctx* c, const dcsg_export_config& cfg, int rank, int world, unsigned flags, dcsg_export_stats& st)
+int export_mesh_stage(dcsg_ctx* c, const dcsg_export_config& cfg, int rank, int world, unsigned flags, dcsg_export_stats& st,
+                      bool project = true)
 {
     int r;
     double t0 = now_s();
@@ -1660,6 +1718,7 @@ int export_mesh_stage(dcsg_ctx* c, const dcsg_export_config& cfg, int rank, int 
         n_tris = c->n_tris;
     }
     st.triangles = n_tris;
+    if (!project) return 0;
 
     t0 = now_s();
     if ((r = dcsg_project_triangles(c, cfg.gradient_descent_steps, c->stream))) return r;
@@ -1686,6 +1745,97 @@ int stage_triangles_on_host(dcsg_ctx* c, float** host)
 }  // namespace
 
 extern "C" {
+
+// Projection, download and both writers of dcsg_export as a pipeline over K chunks of the triangle buffer: while the
+// host formats and writes chunk k, the GPU projects chunk k+1 and the copy engine downloads it.  Exact by
+// construction: projection is a pure function of a vertex's position, so the order in which vertices are projected
+// cannot change a bit; chunks are cut at triangle counts that are multiples of 256, where the scanned owner counts of
+// the de-duplication give the compact-list boundary directly (every triangle before the cut refers only to owners
+// before it: owners are the first occurrences, in buffer order).
+int project_download_write(dcsg_ctx* c, int steps, const char* stl_path, const char* ply_path, unsigned flags, dcsg_export_stats& st)
+{
+    const uint64_t T = c->n_tris;
+    const bool reference_writers = !(flags & (DCSG_EXPORT_INDEXED_PLY | DCSG_EXPORT_STL_NORMALS));
+    const char* env = getenv("DCSG_EXPORT_CHUNKS");
+    int K = env ? atoi(env) : 4;
+    if (K > 8) K = 8;
+    // Not for the tile-culling kernels: their projection is bound by the 50 dependent steps of a wave, not by throughput,
+    // so a launch over a quarter of the vertices takes almost as long as one over all of them (flat256 1024^3: 41 ms in
+    // 4 chunks against 15 ms in one).
+    if (K < 2 || T < 200000 || !reference_writers || !(stl_path || ply_path) || T * 3 > (1ull << 30) || c->variant == 4) return 1;
+    int r = need_scene(c);
+    if (r) return r;
+    const double t0 = now_s();
+    uint64_t Tb[9];
+    for (int k = 0; k <= K; k++) Tb[k] = k == K ? T : ((T * (uint64_t)k / (uint64_t)K) & ~(uint64_t)255);
+    const bool dedup = dedup_applies(c, steps);
+    unsigned Sb[9] = {0};
+    Dedup d;
+    if (dedup) {
+        unsigned probe[8], got[8];
+        for (int k = 1; k < K; k++) probe[k - 1] = (unsigned)(3 * Tb[k] / DCSG_BLOCK);
+        if ((r = dedup_prepare(c, c->stream, d, probe, got, K - 1))) return r;
+        for (int k = 1; k < K; k++) Sb[k] = got[k - 1];
+        Sb[K] = d.n_unique;
+    }
+    size_t need = (size_t)T * 9 * sizeof(float) + 64;
+    if (need > c->h_pinned_cap) {
+        if (c->h_pinned) hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr;
+        c->h_pinned_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_pinned, need + need / 4, hipHostMallocDefault));
+        c->h_pinned_cap = need + need / 4;
+    }
+    float* host = (float*)c->h_pinned;
+    float* d_tris = (float*)c->d_tris.p;
+    for (int k = 0; k < K; k++) {
+        const uint64_t t_lo = Tb[k], t_n = Tb[k + 1] - Tb[k];
+        if (steps > 0) {
+            if (dedup) {
+                if ((r = dcsg_project_vertices_device(c, (float*)c->d_dd_compact.p + (size_t)Sb[k] * 3, Sb[k + 1] - Sb[k], steps, c->stream))) return r;
+                if ((r = dedup_scatter(c, c->stream, (unsigned)(3 * t_lo), (unsigned)(3 * t_n)))) return r;
+            } else if ((r = dcsg_project_vertices_device(c, d_tris + t_lo * 9, (size_t)t_n * 3, steps, c->stream))) {
+                return r;
+            }
+        }
+        HIPCHK(c, hipEventRecord(c->chunk_ready[k], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->chunk_ready[k], 0));
+        if (t_n) HIPCHK(c, hipMemcpyAsync(host + t_lo * 9, d_tris + t_lo * 9, (size_t)t_n * 9 * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->chunk_done[k], c->copy_stream));
+    }
+    double t_last_chunk = 0;
+    auto writer = [&](const char* path, bool ply, int& rc, double& busy) {
+        const double a = now_s();
+        hipSetDevice(c->device);
+        for (int k = 0; k < K && !rc; k++) {
+            if (hipEventSynchronize(c->chunk_done[k]) != hipSuccess) {
+                rc = DCSG_ERR_HIP;
+                break;
+            }
+            if (k == K - 1 && !ply) t_last_chunk = now_s();
+            const unsigned fl = (k == 0 ? DCSG_WRITE_BEGIN : 0u) | (k == K - 1 ? DCSG_WRITE_END : 0u);
+            rc = write_range(path, host + Tb[k] * 9, Tb[k + 1] - Tb[k], Tb[k], T, fl, ply);
+        }
+        busy = now_s() - a;
+    };
+    int rc_stl = 0, rc_ply = 0;
+    double dt_stl = 0, dt_ply = 0;
+    std::thread ply_thread;
+    if (ply_path) ply_thread = std::thread([&] { writer(ply_path, true, rc_ply, dt_ply); });
+    if (stl_path) writer(stl_path, false, rc_stl, dt_stl);
+    if (ply_thread.joinable()) ply_thread.join();
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the stages overlap: t_project = until the last chunk was on the host (projection + its share of the downloads),
+    // the writers' times include their waiting for chunks
+    st.t_project = (t_last_chunk ? t_last_chunk : now_s()) - t0;
+    st.t_download = 0;
+    st.t_write_stl = dt_stl;
+    st.t_write_ply = dt_ply;
+    if (rc_stl) return fail(c, rc_stl, "cannot write STL");
+    if (rc_ply) return fail(c, rc_ply, "cannot write PLY");
+    return 0;
+}
 
 // One Z slab of the export, stages A .. projection (no files): what each rank of a sharded export runs.
 int dcsg_export_slab(dcsg_ctx* c, const char* cfg_txt, int rank, int world, unsigned flags, dcsg_export_stats* stats)
@@ -1792,8 +1942,22 @@ int dcsg_export(dcsg_ctx* c, const char* cfg_txt, const char* stl_path, const ch
     dcsg_export_stats st;
     memset(&st, 0, sizeof(st));
     double t_start = now_s(), t0;
-    if ((r = export_mesh_stage(c, cfg, 0, 1, flags, st))) return r;
+    if ((r = export_mesh_stage(c, cfg, 0, 1, flags, st, false))) return r;
     const uint64_t n_tris = st.triangles;
+
+    // projection + download + writers: pipelined over chunks where that applies (large meshes, reference-layout files) ...
+    r = getenv("DCSG_NO_PIPELINE") ? 1 : project_download_write(c, cfg.gradient_descent_steps, stl_path, ply_path, flags, st);
+    if (r < 0) return r;
+    if (r == 0) {
+        st.t_total = now_s() - t_start;
+        if (stats) *stats = st;
+        return 0;
+    }
+    // ... otherwise one after the other
+    t0 = now_s();
+    if ((r = dcsg_project_triangles(c, cfg.gradient_descent_steps, c->stream))) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    st.t_project = now_s() - t0;
 
     if (stl_path || ply_path) {
         t0 = now_s();

@@ -357,8 +357,10 @@ __device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
     const float lo = 0x1p-60f, hi = 0x1p60f;
     // components are at most len (1 + 2^-22) in magnitude; a zero, tiny, huge or NaN operand anywhere in the wave
     // sends the wave through the plain divisions (zero components: lattice points on a symmetry plane)
-    const bool plain = !(len >= lo && len <= hi && __builtin_fabsf(x) >= lo && __builtin_fabsf(y) >= lo &&
-                         __builtin_fabsf(z) >= lo);
+    // (len >= every |component| -- the root is correctly rounded and monotone --, so len >= lo follows from the smallest
+    // component; a NaN component makes len NaN, which fails len <= hi)
+    const float smallest = __builtin_fminf(__builtin_fminf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z));
+    const bool plain = !(smallest >= lo && len <= hi);
     if (__builtin_amdgcn_ballot_w64(plain) == 0ull) {
         float r = __builtin_amdgcn_rcpf(len);
         float e = __builtin_fmaf(-len, r, 1.0f);
@@ -2068,9 +2070,8 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
 // (mesh.hpp:283-307), so every surface vertex appears about six times; performGradientDescent moves each copy
 // by the same function of its position (mesh.hpp:564-570), so projecting one representative per distinct
 // position and copying the result is exact.  Keys are the three float bit patterns; open addressing with
-// atomicCAS; the owner of a position is whichever copy claims its slot first (the value written back is the
-// same for any choice).  Owners are compacted in buffer order, which keeps neighbours in the mesh neighbours in
-// the compact list (spatial coherence for the tile culling).
+// atomicCAS; the owner of a position is its first copy in the buffer (lowest index).  Owners are compacted in buffer
+// order, which keeps neighbours in the mesh neighbours in the compact list (spatial coherence for the tile culling).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned int dcsg_hash3(unsigned int a, unsigned int b, unsigned int c)
 {
@@ -2081,6 +2082,10 @@ __device__ __forceinline__ unsigned int dcsg_hash3(unsigned int a, unsigned int 
     return h * 0x27D4EB2Fu;
 }
 
+// Pass 1: every vertex finds the table slot of its position; the slot ends up holding the LOWEST index among the
+// copies (atomicMin), so that the owner of a position is its first occurrence in the buffer -- independent of the
+// order in which threads arrive, and what lets the export project and write the mesh in chunks (every triangle before
+// a cut refers only to owners before it).  rep[v] = the slot, resolved to the owner by dcsg_dedup_resolve.
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_dedup_insert(const float* __restrict__ verts, unsigned int n, unsigned int* __restrict__ table, unsigned int mask,
                   unsigned int* __restrict__ rep)
@@ -2091,17 +2096,22 @@ dcsg_dedup_insert(const float* __restrict__ verts, unsigned int n, unsigned int*
         unsigned int h = dcsg_hash3(a, b, c) & mask;
         for (;;) {
             unsigned int old = atomicCAS(&table[h], 0xffffffffu, v);
-            if (old == 0xffffffffu) {
-                rep[v] = v;
-                break;
-            }
+            if (old == 0xffffffffu) break;
+            // whichever copy the slot names at this moment has the slot's position
             if (vb[(size_t)old * 3] == a && vb[(size_t)old * 3 + 1] == b && vb[(size_t)old * 3 + 2] == c) {
-                rep[v] = old;
+                atomicMin(&table[h], v);
                 break;
             }
             h = (h + 1u) & mask;
         }
+        rep[v] = h;
     }
+}
+// Pass 2: rep[v] = the owner (lowest-index copy) of v's position
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_dedup_resolve(const unsigned int* __restrict__ table, unsigned int n, unsigned int* __restrict__ rep)
+{
+    for (unsigned int v = blockIdx.x * DCSG_BLOCK + threadIdx.x; v < n; v += gridDim.x * DCSG_BLOCK) rep[v] = table[rep[v]];
 }
 
 // per-block count of owners (rep[v] == v) in block_sums[2*b] (second word unused: dcsg_scan_blocks scans pairs)
@@ -2146,11 +2156,12 @@ dcsg_dedup_gather(const float* __restrict__ verts, const unsigned int* __restric
 }
 
 // every copy takes the projected position of its representative
+// (copies [first, first + n): the export projects and writes the mesh in chunks)
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_dedup_scatter(float* __restrict__ verts, const unsigned int* __restrict__ rep, const unsigned int* __restrict__ slot_of,
-                   const float* __restrict__ compact, unsigned int n)
+                   const float* __restrict__ compact, unsigned int first, unsigned int n)
 {
-    for (unsigned int v = blockIdx.x * DCSG_BLOCK + threadIdx.x; v < n; v += gridDim.x * DCSG_BLOCK) {
+    for (unsigned int v = first + blockIdx.x * DCSG_BLOCK + threadIdx.x; v < first + n; v += gridDim.x * DCSG_BLOCK) {
         unsigned int s = slot_of[rep[v]];
         verts[(size_t)v * 3 + 0] = compact[(size_t)s * 3 + 0];
         verts[(size_t)v * 3 + 1] = compact[(size_t)s * 3 + 1];

@@ -217,3 +217,25 @@ def test_export_multi_through_the_c_boundary(ev, tmp_path):
     finally:
         for e in evs:
             e.close()
+
+
+@pytest.mark.parametrize("name,levels", [("design2", (7, 9, 10)), ("sphere", (6, 8, 9))])
+def test_pipelined_export_equals_sequential(ev, name, levels, tmp_path, monkeypatch):
+    """dcsg_export projects, downloads and writes large meshes as a pipeline over chunks of the triangle buffer (GPU on
+    chunk k+1 while the host writes chunk k).  Projection is a pure function of a vertex's position, so the files and the
+    device buffer must equal those of the one-after-the-other path bit for bit -- including with a different chunk count."""
+    s = read_scene(name)
+    assert ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
+    cfg_txt = export_config_text(name, levels=list(levels), gd=50)
+    monkeypatch.setenv("DCSG_NO_PIPELINE", "1")
+    a = ev.export(cfg_txt, str(tmp_path / "a.stl"), str(tmp_path / "a.ply"))
+    ta = ev.download_triangles()
+    monkeypatch.delenv("DCSG_NO_PIPELINE")
+    for chunks in (None, "7"):
+        if chunks:
+            monkeypatch.setenv("DCSG_EXPORT_CHUNKS", chunks)
+        b = ev.export(cfg_txt, str(tmp_path / "b.stl"), str(tmp_path / "b.ply"))
+        tb = ev.download_triangles()
+        assert a.triangles == b.triangles and np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+        assert (tmp_path / "a.stl").read_bytes() == (tmp_path / "b.stl").read_bytes()
+        assert (tmp_path / "a.ply").read_bytes() == (tmp_path / "b.ply").read_bytes()
