@@ -31,7 +31,7 @@ namespace dcsg {
 static const char* kIsa = "amdgcn-amd-amdhsa--gfx950";
 
 // libamd_comgr is loaded by absolute path from the ROCm installation whose compiler produced
-// dcsg_kernels_extern.bc, with RTLD_LOCAL | RTLD_DEEPBIND.  A PyTorch process already holds a
+// the kernel bitcode (dcsg_kernels_*.bc), with RTLD_LOCAL | RTLD_DEEPBIND.  A PyTorch process already holds a
 // bundled libamd_comgr.so.3 (older LLVM, same SONAME) that cannot read this bitcode, so linking
 // against the SONAME would silently pick the wrong one.
 struct ComgrApi {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Splits a kernel's disassembly (tools/disasm_scene.py output) into basic blocks and prints, per block, its address
 range, instruction-class counts and where it branches -- enough to find the hot loop and count its VALU work offline.
-    python tools/disasm_scene.py sphere dcsg_sweep_sp2 > /tmp/k.s && python tools/isa_blocks.py /tmp/k.s"""
+    python tools/disasm_scene.py sphere dcsg_sweep_sp_f > /tmp/k.s && python tools/isa_blocks.py /tmp/k.s"""
 import re
 import sys
 
