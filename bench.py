@@ -186,7 +186,7 @@ def export_wall_clock(ev=None):
     return out
 
 
-def profiled_traffic(kernel, workload):
+def profiled_traffic(kernel, workload, numerics="exact"):
     """HBM bytes per launch of `kernel` from the committed PMC summaries (profiles/<tag>_pmc_summary.json:
     separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this same command, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950), taken from the newest profile of the same workload."""
@@ -199,7 +199,8 @@ def profiled_traffic(kernel, workload):
             pmc = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if b.get("config", {}).get("workload") == workload and kernel in pmc and "hbm_bytes_per_launch" in pmc[kernel]:
+        if b.get("config", {}).get("workload") == workload and b.get("config", {}).get("numerics", "exact") == numerics \
+                and kernel in pmc and "hbm_bytes_per_launch" in pmc[kernel]:
             best = (pmc[kernel]["hbm_bytes_per_launch"]["total"], "profiles/" + os.path.basename(f),
                     pmc[kernel]["counters_mean_per_launch"].get("SQ_INSTS_VALU"))
     return best
@@ -415,7 +416,7 @@ def main():
                                                    note="the same %d^3 lattice swept by rank 0's GPU alone (kernel time)" % n1)
         if sdf_only:
             out["sdf_only_sweep"] = sdf_only
-        tr = profiled_traffic(kernel, workload) if world == 1 else None
+        tr = profiled_traffic(kernel, workload, args.numerics) if world == 1 else None
         if tr:
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_source"] = tr[1]
