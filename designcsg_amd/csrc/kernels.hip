@@ -2099,7 +2099,7 @@ dcsg_dedup_insert(const float* __restrict__ verts, unsigned int n, unsigned int*
             if (old == 0xffffffffu) break;
             // whichever copy the slot names at this moment has the slot's position
             if (vb[(size_t)old * 3] == a && vb[(size_t)old * 3 + 1] == b && vb[(size_t)old * 3 + 2] == c) {
-                atomicMin(&table[h], v);
+                if (v < old) atomicMin(&table[h], v);  // the slot's index only ever decreases: nothing to do for a later copy
                 break;
             }
             h = (h + 1u) & mask;
