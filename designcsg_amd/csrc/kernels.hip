@@ -1055,12 +1055,13 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                 dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, want_sdf, want_nrm, sd, nx, ny, nz);
             }
             // wave-uniform base + lane: the store addresses cost no per-lane multiplies
-            if (want_sdf) (sdf_out + idx0)[lane] = sd;
+            // write-once streaming output: non-temporal stores (nothing in this kernel reads the lattice back)
+            if (want_sdf) __builtin_nontemporal_store(sd, (sdf_out + idx0) + lane);
             if (want_nrm) {
                 float* o = nrm_out + (size_t)idx0 * 3 + lane * 3u;
-                o[0] = nx;
-                o[1] = ny;
-                o[2] = nz;
+                __builtin_nontemporal_store(nx, o);
+                __builtin_nontemporal_store(ny, o + 1);
+                __builtin_nontemporal_store(nz, o + 2);
             }
             idx0 += DCSG_WAVE;
         };
