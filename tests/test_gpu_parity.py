@@ -190,6 +190,14 @@ def test_headless_run_export_and_preview(oracle, tmp_path):
     assert ppm.startswith(b"P6\n640 480\n255\n") and len(ppm) == 15 + 640 * 480 * 3
     img = np.frombuffer(ppm[15:], dtype=np.uint8).reshape(480, 640, 3)
     assert np.array_equal(img, osc.render_preview([0, 0, -15], [1, 0, 0], [0, 1, 0], [0, 0, 1]))
+    # the same export sharded over "two GPUs" in one process (--devices: dcsg_export_multi; here both contexts on GPU 0)
+    r = subprocess.run([sys.executable, "-m", "designcsg_amd.run", design, "--workdir", str(tmp_path / "wd2"),
+                        "--export", str(tmp_path / "out2"), "--devices", "0,0"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "on 2 GPUs" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    stl2 = (tmp_path / "out2.stl").read_bytes()
+    assert len(stl2) == len(stl) and os.path.getsize(tmp_path / "out2.ply") == os.path.getsize(tmp_path / "out.ply")
+    got2 = np.frombuffer(stl2[84:], dtype=np.uint8).reshape(-1, 50)[:, 12:48].copy().view(np.float32).reshape(-1, 3, 3)
+    assert np.array_equal(sorted_tris(got2[:, :, [0, 2, 1]]), sorted_tris(want))
 
 
 @pytest.mark.parametrize("seed", list(range(6)))
