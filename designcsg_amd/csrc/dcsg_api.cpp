@@ -39,7 +39,7 @@ struct DevBuf {
 // module only: needs the known Lipschitz bounds of the built-in brushes; eval_points[4] aliases [1]).
 struct Kernels {
     hipFunction_t sweep[5] = {}, eval_points[5] = {}, bbox[5] = {}, project[5] = {};
-    hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr;
+    hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr, test_normal = nullptr;
     hipFunction_t sweep_d[4] = {}, sweep_f[4] = {};  // sweep[v] with the outputs fixed at compile time: SDF only / SDF + normals
     hipFunction_t sweep_nodes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // node-wise sweep per variant
     hipFunction_t dd_insert = nullptr, dd_resolve = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
@@ -172,6 +172,7 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind)
         hipFunction_t* f;
     } tab[] = {{"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan}, {"dcsg_mesh_emit", &k.emit},
                {"dcsg_test_sqrt", &k.test_sqrt},       {"dcsg_dedup_insert", &k.dd_insert},
+               {"dcsg_test_normal", &k.test_normal},
                {"dcsg_dedup_count", &k.dd_count},      {"dcsg_dedup_gather", &k.dd_gather},
                {"dcsg_dedup_scatter", &k.dd_scatter},  {"dcsg_dedup_resolve", &k.dd_resolve},
                {"dcsg_retopo_mark", &k.rt_mark},
@@ -1561,6 +1562,16 @@ int dcsg_debug_sqrt_device(dcsg_ctx* c, const float* d_in, size_t n, float* d_ou
     unsigned cnt = (unsigned)n;
     void* args[] = {(void*)&d_in, (void*)&d_out, &cnt};
     hipFunction_t f = (c->scene_loaded && c->jit) ? c->ks.test_sqrt : c->kb.test_sqrt;
+    return launch(c, f, (unsigned)c->n_cu * 16u, DCSG_BLOCK, 0, (hipStream_t)stream, args);
+}
+
+int dcsg_debug_normal_device(dcsg_ctx* c, const float* d_in, size_t n, float dy, float dz, int mixed, float* d_out, void* stream)
+{
+    if (!c || n > 0x55555500ull) return DCSG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned cnt = (unsigned)n;
+    void* args[] = {(void*)&d_in, (void*)&d_out, &cnt, &dy, &dz, &mixed};
+    hipFunction_t f = (c->scene_loaded && c->jit) ? c->ks.test_normal : c->kb.test_normal;
     return launch(c, f, (unsigned)c->n_cu * 16u, DCSG_BLOCK, 0, (hipStream_t)stream, args);
 }
 

@@ -351,9 +351,11 @@ __device__ __forceinline__ void dcsg_finish_normal(float Dx, float Dy, float Dz,
 }
 #else
 // OpenCL normalize(float3) pinned as v / length(v), zero vector stays zero.
-__device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
+// dcsg_normalize_fast: the quotients through one shared reciprocal when every lane of the wave has ordinary operands
+// (returns true); otherwise nothing is written and the caller takes dcsg_normalize_plain.
+__device__ __forceinline__ bool dcsg_normalize_fast(float& x, float& y, float& z, float& len)
 {
-    float len = dcsg_sqrt(x * x + y * y + z * z);
+    len = dcsg_sqrt(x * x + y * y + z * z);
     const float lo = 0x1p-60f, hi = 0x1p60f;
     // components are at most len (1 + 2^-22) in magnitude; a zero, tiny, huge or NaN operand anywhere in the wave
     // sends the wave through the plain divisions (zero components: lattice points on a symmetry plane)
@@ -361,14 +363,18 @@ __device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
     // component; a NaN component makes len NaN, which fails len <= hi)
     const float smallest = __builtin_fminf(__builtin_fminf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z));
     const bool plain = !(smallest >= lo && len <= hi);
-    if (__builtin_amdgcn_ballot_w64(plain) == 0ull) {
-        float r = __builtin_amdgcn_rcpf(len);
-        float e = __builtin_fmaf(-len, r, 1.0f);
-        float r1 = __builtin_fmaf(e, r, r);
-        x = dcsg_div_by(x, len, r1);
-        y = dcsg_div_by(y, len, r1);
-        z = dcsg_div_by(z, len, r1);
-    } else if (len == 0.0f) {
+    if (__builtin_amdgcn_ballot_w64(plain) != 0ull) return false;
+    float r = __builtin_amdgcn_rcpf(len);
+    float e = __builtin_fmaf(-len, r, 1.0f);
+    float r1 = __builtin_fmaf(e, r, r);
+    x = dcsg_div_by(x, len, r1);
+    y = dcsg_div_by(y, len, r1);
+    z = dcsg_div_by(z, len, r1);
+    return true;
+}
+__device__ __forceinline__ void dcsg_normalize_plain(float& x, float& y, float& z, float len)
+{
+    if (len == 0.0f) {
         x = y = z = 0.0f;
     } else {
         x = x / len;
@@ -376,16 +382,34 @@ __device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
         z = z / len;
     }
 }
+__device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
+{
+    float len;
+    if (!dcsg_normalize_fast(x, y, z, len)) dcsg_normalize_plain(x, y, z, len);
+}
 
-// tail of get_normal, k2.cl:175-177: "1.0/twoE*Dx" is a double product narrowed by the float3 cast
+// tail of get_normal, k2.cl:175-177: "1.0/twoE*Dx" is a double product narrowed by the float3 cast.
+// With k = 1 / (double)twoE split into kh + kl (two floats), fma(kh, D, kl * D) equals (float)(k * (double)D) for EVERY
+// float D with |D| >= 2^-111, and for zeros, infinities and NaNs (all 2^32 bit patterns compared on the GPU:
+// tools/gradscale_probe.hip, tests/test_gpu_parity.py::test_normal_all_float_inputs); below that kl * D loses bits
+// to underflow.  Such a component scales to less than 2^-104, which dcsg_normalize_fast refuses (2^-60), and a wave
+// it refuses redoes the scale in double precision: three multiplies and three FMAs replace six conversions and three
+// double multiplies on every wave that matters.
 __device__ __forceinline__ void dcsg_finish_normal(float Dx, float Dy, float Dz, float& nx, float& ny, float& nz)
 {
     const float twoE = (float)(2.0 * K2_NORMAL_EPSILON);
     const double k = 1.0 / (double)twoE;
+    const float kh = (float)k, kl = (float)(k - (double)kh);
+    nx = __builtin_fmaf(kh, Dx, kl * Dx);
+    ny = __builtin_fmaf(kh, Dy, kl * Dy);
+    nz = __builtin_fmaf(kh, Dz, kl * Dz);
+    float len;
+    if (dcsg_normalize_fast(nx, ny, nz, len)) return;
     nx = (float)(k * (double)Dx);
     ny = (float)(k * (double)Dy);
     nz = (float)(k * (double)Dz);
-    dcsg_normalize(nx, ny, nz);
+    len = dcsg_sqrt(nx * nx + ny * ny + nz * nz);
+    dcsg_normalize_plain(nx, ny, nz, len);
 }
 #endif
 
@@ -2384,6 +2408,19 @@ extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_test_sqrt(const float* __restrict__ in, float* __restrict__ out, unsigned int n)
 {
     for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < n; i += gridDim.x * DCSG_BLOCK) out[i] = dcsg_sqrt(in[i]);
+}
+
+// Diagnostic: dcsg_finish_normal(in[i], dy, dz) over an array (exhaustive test of the float-only gradient scale).
+// mixed: odd lanes take the gradient (1, 2, 3) instead, so a wave holds ordinary and extreme operands side by side.
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_test_normal(const float* __restrict__ in, float* __restrict__ out, unsigned int n, float dy, float dz, int mixed)
+{
+    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < n; i += gridDim.x * DCSG_BLOCK) {
+        float nx, ny, nz;
+        const bool other = mixed && (i & 1u);
+        dcsg_finish_normal(other ? 1.0f : in[i], other ? 2.0f : dy, other ? 3.0f : dz, nx, ny, nz);
+        out[3u * i] = nx, out[3u * i + 1u] = ny, out[3u * i + 2u] = nz;
+    }
 }
 
 #if defined(DCSG_EXTERN_BANK) && !defined(DCSG_SET_SPEC)

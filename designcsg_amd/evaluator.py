@@ -190,6 +190,11 @@ class Evaluator:
     def debug_sqrt_device(self, d_in, n, d_out, stream=0):
         self._ck(self._L.dcsg_debug_sqrt_device(self._h, C.c_void_p(d_in), n, C.c_void_p(d_out), C.c_void_p(stream or None)))
 
+    def debug_normal_device(self, d_in, n, dy, dz, mixed, d_out, stream=0):
+        """Diagnostic: normals of the gradients (in[i], dy, dz) as the kernels' get_normal tail computes them."""
+        self._ck(self._L.dcsg_debug_normal_device(self._h, C.c_void_p(d_in), n, dy, dz, int(mixed), C.c_void_p(d_out),
+                                                  C.c_void_p(stream or None)))
+
     def render_preview(self, campos=(0.0, 0.0, -15.0), right=(1.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), forward=(0.0, 0.0, 1.0)):
         """Kernel k1: the 640x480 preview of the loaded scene as a (480, 640, 3) uint8 array."""
         v = [np.ascontiguousarray(a, dtype=np.float32) for a in (campos, right, up, forward)]

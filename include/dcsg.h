@@ -246,6 +246,10 @@ float dcsg_angle_q_star(float complex_surface_threshold);
 
 /* Diagnostic: the kernels' correctly rounded square root over a device array (exhaustive GPU test). */
 int dcsg_debug_sqrt_device(dcsg_ctx* ctx, const float* d_in, size_t n, float* d_out, void* stream);
+/* Diagnostic: the tail of get_normal (k2.cl:175-177: gradient scale in double, normalize) as the kernels compute it,
+ * d_out[3i..3i+2] = normal of the gradient (d_in[i], dy, dz); mixed != 0: odd elements take (1, 2, 3) instead, so a
+ * wave holds ordinary and extreme operands together (exhaustive GPU test of the float-only scale). */
+int dcsg_debug_normal_device(dcsg_ctx* ctx, const float* d_in, size_t n, float dy, float dz, int mixed, float* d_out, void* stream);
 
 /* The compile half of Evaluator::build without a device: compiles scene_cl into the on-disk code
  * object cache (used at install time so that known scenes load without compiling).  The compiler

@@ -513,6 +513,77 @@ def test_sqrt_all_float_inputs(ev, module):
         del bits
 
 
+def _normal_tail_numpy(d, dy, dz):
+    """get_normal's tail (k2.cl:175-177 + normalize pinned as v / length(v)) in IEEE float / double arithmetic."""
+    k = 1.0 / np.float64(np.float32(2.0 * 0.005))
+    with np.errstate(all="ignore"):
+        n = [(k * c.astype(np.float64)).astype(np.float32) for c in (d, dy, dz)]
+        q = n[0] * n[0]
+        q = q + n[1] * n[1]
+        q = q + n[2] * n[2]
+        ln = np.sqrt(q)
+        zero = ln == 0
+        return [np.where(zero, np.float32(0), c / ln) for c in n]
+
+
+def _normal_tail_torch(d, dy, dz):
+    """The same on the GPU with every rounding made explicit: products / sums as separate float kernels, square root and
+    quotients in double and narrowed (innocuous double rounding for normal results: 53 >= 2 * 24 + 2)."""
+    import torch
+    k = 1.0 / float(np.float64(np.float32(2.0 * 0.005)))
+    n = [torch.mul(c.double(), k).float() for c in (d, dy, dz)]
+    q = torch.mul(n[0], n[0])
+    q = torch.add(q, torch.mul(n[1], n[1]))
+    q = torch.add(q, torch.mul(n[2], n[2]))
+    ln = torch.sqrt(q.double()).float()
+    zero = ln == 0
+    return [torch.where(zero, torch.zeros_like(c), (c.double() / ln.double()).float()) for c in n]
+
+
+@pytest.mark.parametrize("module", ["builtin", "scene"])
+def test_normal_all_float_inputs(ev, module):
+    """The tail of get_normal as the kernels compute it -- gradient scale by float-only arithmetic where that is exact,
+    in double where a wave holds a component below 2^-60 after scaling -- for EVERY binary32 bit pattern of the first
+    gradient component (builtin module; every 8th block of 2^26 for the scene module), alone in its waves and next
+    to ordinary lanes.  Reference: numpy float / double arithmetic for the blocks with tiny |D| (subnormal quotients),
+    explicit double-rounded torch arithmetic on the GPU elsewhere, cross-checked against numpy on one block."""
+    import torch
+    if module == "scene":
+        load(ev, "design2")
+    else:
+        s = read_scene("flat256")
+        assert ev.build(s["scene.txt"], s["buildprocedure.txt"], None)[0] == 0 and not ev.scene_info()["jit"]
+    stream = torch.cuda.current_stream().cuda_stream
+    chunk = 1 << 26
+    step = 1 if module == "builtin" else 8
+    out = torch.empty(3 * chunk, dtype=torch.float32, device="cuda")
+    dy, dz = 0.25, -0.5
+    odd = (torch.arange(chunk, device="cuda") & 1).bool()
+    for ci, c in enumerate(range(0, 1 << 32, chunk * step)):
+        x = (torch.arange(c, c + chunk, dtype=torch.int64, device="cuda") - (1 << 32) * (c >= (1 << 31))).to(torch.int32).view(torch.float32)
+        for mixed in ((0, 1) if ci % 4 == 0 else (0,)):
+            ev.debug_normal_device(x.data_ptr(), chunk, dy, dz, mixed, out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            d = torch.where(odd, torch.full_like(x, 1.0), x) if mixed else x
+            y = torch.where(odd, torch.full_like(x, 2.0), torch.full_like(x, dy)) if mixed else torch.full_like(x, dy)
+            z = torch.where(odd, torch.full_like(x, 3.0), torch.full_like(x, dz)) if mixed else torch.full_like(x, dz)
+            got = out.view(chunk, 3)
+            tiny = (c & 0x7fffffff) < (1 << 28)          # |D| < 2^-95: quotients can be subnormal
+            if tiny or c == 0x40000000:
+                want = _normal_tail_numpy(d.cpu().numpy(), y.cpu().numpy(), z.cpu().numpy())
+                g = got.cpu().numpy()
+                for k in range(3):
+                    nan = np.isnan(want[k])
+                    assert np.array_equal(np.isnan(g[:, k]), nan), (hex(c), mixed, k)
+                    assert np.array_equal(g[:, k][~nan].view(np.uint32), want[k][~nan].view(np.uint32)), (hex(c), mixed, k)
+            if not tiny:
+                want = _normal_tail_torch(d, y, z)
+                for k in range(3):
+                    w, g = want[k], got[:, k]
+                    same = (w.view(torch.int32) == g.view(torch.int32)) | (torch.isnan(w) & torch.isnan(g))
+                    assert bool(same.all()), (hex(c), mixed, k, int((~same).sum()))
+
+
 def test_set_arbitrary_data_after_build(ev, oracle):
     """Evaluator::setArbitraryData (Evaluator.cpp:213-225) on a loaded scene: the brushes see the new table."""
     s = load(ev, "ad_table")
