@@ -422,12 +422,16 @@ def main():
             out["roofline"]["traffic_source"] = tr[1]
             if tr[2]:
                 # what actually bounds the kernel: wave64 VALU instructions issued per launch (PMC,
-                # same profile) against 256 CU x 4 SIMD x one instruction per 4 cycles at the 2.4 GHz peak clock
-                peak = 256 * 4 * 2.4e9 / 4
+                # same profile) against the issue rate of plain f32 VALU instructions MEASURED on this chip
+                # (tools/pk_rate_probe.hip, profiles/r02_pk_rate_probe.txt: v_fma_f32 8.27e11, v_mul_f32 8.55e11
+                # wave-instructions/s over 256 CUs; v_sqrt_f32 3.0e11, compare + select 6.7e11, v_mul_f64 4.5e11 -- the
+                # kernel's mix of those prices the exact sweep at 0.56 ms)
+                peak = 8.27e11
                 rate = tr[2] / (kernel_ms * 1e-3)
                 out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": tr[2],
                                                  "per_lattice_point": round(tr[2] * 64 / own_points, 1),
                                                  "achieved_per_s": round(rate, 0), "peak_per_s": peak,
+                                                 "peak_source": "measured v_fma_f32 issue rate (profiles/r02_pk_rate_probe.txt)",
                                                  "frac": round(rate / peak, 4)}
         if world == 1 and not args.no_secondary:
             out["secondary_sweeps"] = secondary_sweeps(scene_dir, local_rank, center, diameter, res)

@@ -43,11 +43,16 @@
 #define OP_SET_K 8
 
 // ---------------------------------------------------------------------------
-// Correctly rounded sqrtf.  v_sqrt_f32 is good to 1 ulp; the IEEE result is obtained by testing the two
-// neighbours with exact FMA residuals -- the same fix-up the compiler emits for __builtin_sqrtf, which
-// additionally rescales inputs below 2^-96 (and patches 0 / inf) on every call.  Here a wave whose inputs
-// are all >= 2^-96 skips that scaffolding (9 instead of 15 VALU instructions; 8 square roots per lattice
-// point in the fused sweep); any other wave (tiny, zero, negative, NaN) takes the compiler's full sequence.
+// Correctly rounded sqrtf from the reciprocal square root: y = v_rsq_f32(x) (1 ulp), g = x y, h = y / 2, then ONE
+// residual correction g + (x - g g) h with both steps as FMAs.  tools/rsq_sqrt_probe.hip compares it with IEEE sqrtf
+// for every positive normal float on gfx950: no difference for any x >= 2^-102 (the residual is exact there and the
+// hardware's rsq is accurate enough that the corrected value never lands on the wrong side of a rounding boundary);
+// below that the result can be off by an ulp, and for 0 / subnormal / inf / negative / NaN inputs (where rsq or x y is
+// inf or NaN) it is NaN or inf -- so a wave in which some lane's first estimate g is not a finite number >= 2^-48
+// (covers every x < 2^-96 and all of those) takes the compiler's full IEEE sequence instead.  Issue cost measured on the chip (tools/instr_cost_probe.hip): rsq 2.4 fma
+// slots + 2 multiplies + 2 FMAs + the guard (integer add + compare), against 2.4 + nine instructions (two integer adds, two FMAs, three
+// compares, two selects -- compares and selects cost 1.4 fma slots each) for the v_sqrt_f32 + neighbour test form the
+// compiler uses and rounds 1-2 shipped.  Eight square roots per lattice point in the fused sweep.
 // tests/test_gpu_parity.py::test_sqrt_all_float_inputs checks all 2^32 bit patterns against IEEE sqrtf.
 // ---------------------------------------------------------------------------
 #ifdef DCSG_RELAXED
@@ -58,15 +63,15 @@ __device__ __forceinline__ float dcsg_sqrt(float x) { return __builtin_amdgcn_sq
 #else
 __device__ __forceinline__ float dcsg_sqrt(float x)
 {
-    float r = __builtin_amdgcn_sqrtf(x);
-    float rm = __uint_as_float(__float_as_uint(r) - 1u);
-    float rp = __uint_as_float(__float_as_uint(r) + 1u);
-    float em = __builtin_fmaf(-rm, r, x);  // x - rm*r, exact sign
-    float ep = __builtin_fmaf(-rp, r, x);  // x - rp*r
-    r = 0.0f >= em ? rm : r;
-    r = 0.0f < ep ? rp : r;
-    // rare: some lane is below 2^-96 (or zero, negative, NaN): override with the compiler's full sequence
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f)) != 0ull, 0)) r = __builtin_sqrtf(x);
+    float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y;
+    float h = 0.5f * y;
+    float d = __builtin_fmaf(-g, g, x);  // x - g*g, exact for x >= 2^-102
+    float r = __builtin_fmaf(d, h, g);
+    // rare: some lane is below 2^-96 (or zero, subnormal, inf, negative, NaN): override with the compiler's full sequence
+    // (the estimate g is a finite number >= 2^-48 exactly when x is an ordinary input: tiny x gives a smaller g, zeros,
+    // +inf, negative numbers and NaNs give NaN, subnormals of either sign +inf; one unsigned range test on its bits)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(__float_as_uint(g) - 0x27800000u < 0x58000000u)) != 0ull, 0)) r = __builtin_sqrtf(x);
     return r;
 }
 #endif
@@ -114,6 +119,7 @@ __device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v)
 typedef float dcsg_cl_float3 __attribute__((ext_vector_type(3)));
 extern "C" __device__ float sdf_bank(dcsg_cl_float3 v, unsigned char shape_id);  // generated scene.cl
 extern "C" __device__ void dcsg_scene_set_ad(__attribute__((address_space(1))) float* p);  // scene_prelude.cl
+extern "C" __device__ float dcsg_sqrt_ieee(float x);                                        // scene_prelude.cl: the brushes' sqrt / length
 // preview only: the scene's materials and the camera basis they may read (scene_epilogue.cl)
 extern "C" __device__ dcsg_cl_float3 shader_bank(dcsg_cl_float3 gv, dcsg_cl_float3 lv, dcsg_cl_float3 n, unsigned char material_id);
 extern "C" __device__ void dcsg_scene_set_camera(dcsg_cl_float3 r, dcsg_cl_float3 u, dcsg_cl_float3 f);
@@ -2403,11 +2409,19 @@ dcsg_retopo_emit(const float* __restrict__ tris, unsigned int n_tris, DcsgRetopo
     }
 }
 
-// Diagnostic: dcsg_sqrt over an array (exhaustive test of the custom square root).
+// Diagnostic: dcsg_sqrt over an array (exhaustive test of the custom square root).  In a scene module the copy the
+// brush text uses (scene_prelude.cl) is evaluated as well and any difference between the two is reported as -1.
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_test_sqrt(const float* __restrict__ in, float* __restrict__ out, unsigned int n)
 {
-    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < n; i += gridDim.x * DCSG_BLOCK) out[i] = dcsg_sqrt(in[i]);
+    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < n; i += gridDim.x * DCSG_BLOCK) {
+        float r = dcsg_sqrt(in[i]);
+#ifdef DCSG_EXTERN_BANK
+        float c = dcsg_sqrt_ieee(in[i]);
+        if (__float_as_uint(c) != __float_as_uint(r) && !(c != c && r != r)) r = -1.0f;
+#endif
+        out[i] = r;
+    }
 }
 
 // Diagnostic: dcsg_finish_normal(in[i], dy, dz) over an array (exhaustive test of the float-only gradient scale).

@@ -26,21 +26,19 @@ float sdf_bank(float3 v, unsigned char shape_id);
 float3 shader_bank(float3 gv, float3 lv, float3 n, unsigned char material_id);
 
 #define DCSG_OVL __attribute__((overloadable))
-/* Correctly rounded sqrtf: same sequence as dcsg_sqrt in kernels.hip (fast path for waves whose inputs are
- * all >= 2^-96, the compiler's full IEEE expansion otherwise). */
+/* Correctly rounded sqrtf: same sequence as dcsg_sqrt in kernels.hip (rsq + one FMA residual correction for waves
+ * whose inputs are all in [2^-96, inf), the compiler's full IEEE expansion otherwise). */
 #ifdef DCSG_RELAXED
 /* opt-in relaxed numerics (dcsg_set_numerics): the hardware square root, 1 ulp */
 float dcsg_sqrt_ieee(float x){ return __builtin_amdgcn_sqrtf(x); }
 #else
 float dcsg_sqrt_ieee(float x){
-    float r = __builtin_amdgcn_sqrtf(x);
-    float rm = as_float(as_uint(r) - 1u);
-    float rp = as_float(as_uint(r) + 1u);
-    float em = __builtin_fmaf(-rm, r, x);
-    float ep = __builtin_fmaf(-rp, r, x);
-    r = 0.0f >= em ? rm : r;
-    r = 0.0f < ep ? rp : r;
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f)) != 0ul, 0)) r = __builtin_sqrtf(x);
+    float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y;
+    float h = 0.5f * y;
+    float d = __builtin_fmaf(-g, g, x);
+    float r = __builtin_fmaf(d, h, g);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(as_uint(g) - 0x27800000u < 0x58000000u)) != 0ul, 0)) r = __builtin_sqrtf(x);
     return r;
 }
 #endif

@@ -8,18 +8,22 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+template <int V>
 __device__ __forceinline__ float sq_rsq(float x)
 {
     float y = __builtin_amdgcn_rsqf(x);
     float g = x * y;
     float h = 0.5f * y;
-    float e = __builtin_fmaf(-h, g, 0.5f);
-    h = __builtin_fmaf(h, e, h);
-    g = __builtin_fmaf(g, e, g);
-    float d = __builtin_fmaf(-g, g, x);
+    if (V == 0 || V == 1 || V == 3) {
+        float e = __builtin_fmaf(-h, g, 0.5f);
+        if (V != 1) h = __builtin_fmaf(h, e, h);      // V1: h left at rsq accuracy
+        if (V != 3) g = __builtin_fmaf(g, e, g);      // V3: g left at rsq accuracy
+    }
+    float d = __builtin_fmaf(-g, g, x);               // V2: one correction straight from the rsq values
     g = __builtin_fmaf(d, h, g);
     return g;
 }
+template <int V>
 __global__ void k(unsigned long long base, unsigned int* bad, unsigned int* first_bad, unsigned int* min_bad_exp, unsigned int* max_bad_exp)
 {
     unsigned long long i = base + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -28,7 +32,7 @@ __global__ void k(unsigned long long base, unsigned int* bad, unsigned int* firs
     if (!(x > 0.0f) || !(x < __builtin_inff())) return;
     if (((b >> 23) & 0xff) == 0) return;  // denormals excluded
     float want = __builtin_sqrtf(x);
-    float got = sq_rsq(x);
+    float got = sq_rsq<V>(x);
     if (__float_as_uint(want) != __float_as_uint(got)) {
         atomicAdd(bad, 1u);
         atomicMin(first_bad, b);
@@ -36,17 +40,26 @@ __global__ void k(unsigned long long base, unsigned int* bad, unsigned int* firs
         atomicMax(max_bad_exp, (b >> 23) & 0xff);
     }
 }
+template <int V>
+void run(unsigned int* d, const char* name)
+{
+    unsigned int init[4] = {0, 0xffffffffu, 255, 0};
+    hipMemcpy(d, init, 16, hipMemcpyHostToDevice);
+    for (unsigned long long base = 0; base < (1ull << 31); base += (1ull << 28))
+        hipLaunchKernelGGL(k<V>, dim3((1u << 28) / 256), dim3(256), 0, 0, base, d, d + 1, d + 2, d + 3);
+    hipDeviceSynchronize();
+    unsigned int out[4];
+    hipMemcpy(out, d, 16, hipMemcpyDeviceToHost);
+    printf("%-58s %u mismatches, first %08x, exponent field %u..%u\n", name, out[0], out[1], out[2], out[3]);
+}
 int main()
 {
     unsigned int* d;
     hipMalloc(&d, 16);
-    unsigned int init[4] = {0, 0xffffffffu, 255, 0};
-    hipMemcpy(d, init, 16, hipMemcpyHostToDevice);
-    for (unsigned long long base = 0; base < (1ull << 31); base += (1ull << 28))
-        hipLaunchKernelGGL(k, dim3((1u << 28) / 256), dim3(256), 0, 0, base, d, d + 1, d + 2, d + 3);
-    hipDeviceSynchronize();
-    unsigned int out[4];
-    hipMemcpy(out, d, 16, hipMemcpyDeviceToHost);
-    printf("rsq-path sqrt over all positive normal floats: %u mismatches, first %08x, exponent range %u..%u\n", out[0], out[1], out[2], out[3]);
+    printf("rsq-path square roots over all positive normal floats against __builtin_sqrtf:\n");
+    run<0>(d, "V0 rsq, 2 mul, 5 fma (h and g refined)");
+    run<1>(d, "V1 rsq, 2 mul, 4 fma (g refined, h not)");
+    run<3>(d, "V3 rsq, 2 mul, 4 fma (h refined, g not)");
+    run<2>(d, "V2 rsq, 2 mul, 2 fma (one correction)");
     return 0;
 }
