@@ -327,18 +327,17 @@ __device__ __forceinline__ float dcsg_primary_sdf(const SceneLds& s, float x, fl
     return export_value;
 }
 
-// n / d exactly as the compiler's IEEE-754 division sequence computes it once v_div_scale_f32 and v_div_fixup_f32
-// are no-ops -- which they are for normal operands away from the ends of the exponent range (here: 2^-60 <= |n|,
-// d <= 2^60 and |n| <= 2 d, so quotient and reciprocal are normal too): r1 is the refined reciprocal, then two
-// residual corrections of the quotient.  Same instructions, same bits; the reciprocal is shared by the three
-// components (tools/fast_div_probe.hip: 1.3e10 operand pairs against `/`, no difference).
+// n / d, correctly rounded, through d's reciprocal refined once (r1, shared by the three components) and ONE residual
+// correction of the quotient.  The compiler's IEEE-754 division does two corrections between v_div_scale_f32 and
+// v_div_fixup_f32 (rounds 1-2 shipped that); tools/div_short_probe.hip compares both with `/` for every pair of float
+// mantissas (2^46 pairs, 40 s on the GPU): neither ever differs, so the second correction never changes a bit.  The
+// quotient's bits depend on the mantissas alone while nothing underflows or overflows, which the caller guarantees
+// (2^-60 <= |n|, d <= 2^60 and |n| <= 2 d: quotient, reciprocal and residual are normal).
 __device__ __forceinline__ float dcsg_div_by(float n, float d, float r1)
 {
     float q = n * r1;
     float e2 = __builtin_fmaf(-d, q, n);
-    float q1 = __builtin_fmaf(e2, r1, q);
-    float e3 = __builtin_fmaf(-d, q1, n);
-    return __builtin_fmaf(e3, r1, q1);
+    return __builtin_fmaf(e2, r1, q);
 }
 
 #ifdef DCSG_RELAXED
