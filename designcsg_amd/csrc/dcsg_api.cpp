@@ -347,6 +347,9 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
         axes_off = (int)lds;
         lds += 3 * n1 * sizeof(float);
     }
+    // diagnostic: unused LDS per block, to hold fewer blocks on a CU (occupancy experiments, tools/ab_sweep.py)
+    static const size_t lds_pad = getenv("DCSG_SWEEP_LDS_PAD") ? (size_t)atol(getenv("DCSG_SWEEP_LDS_PAD")) : 0;
+    if (lds + lds_pad <= 160 * 1024) lds += lds_pad;
     for (uint64_t p0 = 0; p0 < (uint64_t)(z1 - z0); p0 += planes_per) {
         uint64_t np = (uint64_t)(z1 - z0) - p0 < planes_per ? (uint64_t)(z1 - z0) - p0 : planes_per;
         unsigned first = (unsigned)(p0 * plane);

@@ -31,17 +31,20 @@ def main():
     a, b = os.path.abspath(sys.argv[1]), os.path.abspath(sys.argv[2])
     opt = lambda n, d: sys.argv[sys.argv.index(n) + 1] if n in sys.argv else d
     scene, level, rounds, numerics = opt("--scene", "sphere"), opt("--level", "9"), int(opt("--rounds", "3")), opt("--numerics", "exact")
-    res = {a: [], b: []}
+    envs = {"A": opt("--env-a", ""), "B": opt("--env-b", "")}   # "KEY=VALUE,KEY2=VALUE2" for one side
+    res = {"A": [], "B": []}
     for r in range(rounds):
-        for t in (a, b):
-            p = subprocess.run([sys.executable, "-c", CHILD, t, scene, level, numerics], capture_output=True, text=True)
+        for name, t in (("A", a), ("B", b)):
+            env = dict(os.environ)
+            env.update(kv.split("=", 1) for kv in envs[name].split(",") if kv)
+            p = subprocess.run([sys.executable, "-c", CHILD, t, scene, level, numerics], capture_output=True, text=True, env=env)
             if p.returncode:
                 sys.exit(p.stderr[-2000:])
-            res[t].append(json.loads(p.stdout.strip().splitlines()[-1]))
-    for t, name in ((a, "A"), (b, "B")):
+            res[name].append(json.loads(p.stdout.strip().splitlines()[-1]))
+    for name, t in (("A", a), ("B", b)):
         for key in ("fused", "sdf_only"):
-            v = [x[key] for x in res[t]]
-            print("%s %-40s %-9s min %.4f  all %s" % (name, os.path.relpath(t), key, min(v), v))
+            v = [x[key] for x in res[name]]
+            print("%s %-34s %-24s %-9s min %.4f  all %s" % (name, os.path.relpath(t), envs[name], key, min(v), v))
 
 
 if __name__ == "__main__":
