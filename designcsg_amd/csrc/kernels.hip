@@ -139,6 +139,7 @@ extern "C" __device__ float dcsg_spec_eval1(float x, float y, float z);
 // dcsg_spec_eval1 with every term of every transform written out: valid for any input (the three above may
 // leave out terms with a zero coefficient, which is exact for finite coordinates only -- specialise.cpp)
 extern "C" __device__ float dcsg_spec_eval1x(float x, float y, float z);
+extern "C" __device__ int dcsg_spec_small();  // 1: few objects, row-invariant stencil terms may stay in registers
 #define DCSG_HAVE_SPEC 1
 #endif
 #else
@@ -1055,6 +1056,35 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             iy0 = t0 - iz0 * n1;
             plane0 = iz0 + (unsigned int)z0;                                // ... to here
         }
+#ifdef DCSG_HAVE_SPEC
+        if (K < 0 && MODE != 0 && ax && left >= DCSG_RUN && ix0 + DCSG_RUN <= n1 && dcsg_spec_small()) {
+            // Small scenes, a whole run inside one lattice row (half of the runs at 513 points per row, three quarters at
+            // 1025): y and z are the same for its four passes, so everything the seven stencil evaluations derive from
+            // them alone is computed once per run (loop-invariant code motion; same operations, same bits), the four x
+            // reads go out together and the per-pass row tests disappear.
+            const float y = ax[n1 + iy0], z = ax[2u * n1 + plane0];
+            const float* xrow = ax + ix0 + lane;
+            auto one = [&](unsigned int k) {
+                float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+                dcsg_stencil_spec<true>(xrow[k * DCSG_WAVE], y, z, true, MODE == 3, sd, nx, ny, nz);
+                __builtin_nontemporal_store(sd, (sdf_out + idx0) + lane + k * DCSG_WAVE);
+                if (MODE == 3) {
+                    float* o = nrm_out + (size_t)idx0 * 3 + (lane + k * DCSG_WAVE) * 3u;
+                    __builtin_nontemporal_store(nx, o);
+                    __builtin_nontemporal_store(ny, o + 1);
+                    __builtin_nontemporal_store(nz, o + 2);
+                }
+            };
+            if (MODE == 1) {
+#pragma unroll
+                for (unsigned int k = 0u; k < DCSG_RUN / DCSG_WAVE; k++) one(k);
+            } else {
+#pragma unroll 1
+                for (unsigned int k = 0u; k < DCSG_RUN / DCSG_WAVE; k++) one(k);
+            }
+            continue;
+        }
+#endif
         auto pass = [&](unsigned int done) {
             float x, y, z;
             if (ax) {

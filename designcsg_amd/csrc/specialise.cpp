@@ -169,11 +169,20 @@ std::string specialised_source(const Scene& s, bool null_brush_const, bool enabl
         out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){ return (float8)(0.0f); }\n";
         out += "float dcsg_spec_eval1(float x, float y, float z){ return 0.0f; }\n";
         out += "float dcsg_spec_eval1x(float x, float y, float z){ return 0.0f; }\n";
+        out += "int dcsg_spec_small(void){ return 0; }\n";
         return out;
     }
     emit_function(s, null_brush_const, 7, simplify, "", out);
     emit_function(s, null_brush_const, 1, simplify, "dcsg_spec_eval1", out);
     emit_function(s, null_brush_const, 1, false, "dcsg_spec_eval1x", out);  // every term written out: any input
+    // dcsg_spec_small: the scene evaluates at most four objects, so the row-invariant part of its seven stencil
+    // evaluations fits in registers and the sweep may keep it across the passes of a run (kernels.hip, dcsg_sweep_body)
+    int evals = 0;
+    for (int c = 0; c < s.n_stack_prog; c++) {
+        const int op = s.stack_prog[4 * c], brush = s.stack_prog[4 * c + 1] & 0xff;
+        if (((op >= 32 && op <= 35) || (op >= 41 && op <= 43)) && !(brush == 0 && null_brush_const)) evals++;
+    }
+    out += std::string("__attribute__((always_inline)) int dcsg_spec_small(void){ return ") + (evals <= 4 ? "1" : "0") + "; }\n";
     return out;
 }
 
