@@ -1057,31 +1057,27 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             plane0 = iz0 + (unsigned int)z0;                                // ... to here
         }
 #ifdef DCSG_HAVE_SPEC
-        if (K < 0 && MODE != 0 && ax && left >= DCSG_RUN && ix0 + DCSG_RUN <= n1 && dcsg_spec_small()) {
-            // Small scenes, a whole run inside one lattice row (half of the runs at 513 points per row, three quarters at
-            // 1025): y and z are the same for its four passes, so everything the seven stencil evaluations derive from
-            // them alone is computed once per run (loop-invariant code motion; same operations, same bits), the four x
-            // reads go out together and the per-pass row tests disappear.
+        // Small scenes: passes that lie inside one lattice row share y and z, so everything the seven stencil evaluations
+        // derive from those two alone is computed once for the passes of a row segment (loop-invariant code motion: same
+        // operations, same bits), and the per-pass row tests disappear.
+        auto row_pass = [&](const float* xrow, float y, float z, unsigned int k) {
+            float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+            dcsg_stencil_spec<true>(xrow[k * DCSG_WAVE], y, z, true, MODE == 3, sd, nx, ny, nz);
+            __builtin_nontemporal_store(sd, (sdf_out + idx0) + lane + k * DCSG_WAVE);
+            if (MODE == 3) {
+                float* o = nrm_out + (size_t)idx0 * 3 + (lane + k * DCSG_WAVE) * 3u;
+                __builtin_nontemporal_store(nx, o);
+                __builtin_nontemporal_store(ny, o + 1);
+                __builtin_nontemporal_store(nz, o + 2);
+            }
+        };
+        if (K < 0 && MODE == 1 && ax && left >= DCSG_RUN && ix0 + DCSG_RUN <= n1 && dcsg_spec_small()) {
+            // SDF only: a whole run inside one row (half of the runs at 513 points per row, three quarters at 1025), its
+            // four x reads issued together, four passes unrolled
             const float y = ax[n1 + iy0], z = ax[2u * n1 + plane0];
             const float* xrow = ax + ix0 + lane;
-            auto one = [&](unsigned int k) {
-                float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
-                dcsg_stencil_spec<true>(xrow[k * DCSG_WAVE], y, z, true, MODE == 3, sd, nx, ny, nz);
-                __builtin_nontemporal_store(sd, (sdf_out + idx0) + lane + k * DCSG_WAVE);
-                if (MODE == 3) {
-                    float* o = nrm_out + (size_t)idx0 * 3 + (lane + k * DCSG_WAVE) * 3u;
-                    __builtin_nontemporal_store(nx, o);
-                    __builtin_nontemporal_store(ny, o + 1);
-                    __builtin_nontemporal_store(nz, o + 2);
-                }
-            };
-            if (MODE == 1) {
 #pragma unroll
-                for (unsigned int k = 0u; k < DCSG_RUN / DCSG_WAVE; k++) one(k);
-            } else {
-#pragma unroll 1
-                for (unsigned int k = 0u; k < DCSG_RUN / DCSG_WAVE; k++) one(k);
-            }
+            for (unsigned int k = 0u; k < DCSG_RUN / DCSG_WAVE; k++) row_pass(xrow, y, z, k);
             continue;
         }
 #endif
@@ -1124,6 +1120,38 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             }
             idx0 += DCSG_WAVE;
         };
+#ifdef DCSG_HAVE_SPEC
+        if (K < 0 && MODE == 3 && ax && left >= DCSG_RUN && dcsg_spec_small()) {
+            // SDF + normals: the run is cut into row segments (the passes up to the end of the current row); a pass that
+            // straddles a row end takes the general code.  7 of 8 passes are inside a row at 513 points per row.
+            unsigned int k = 0u;
+            while (k < DCSG_RUN / DCSG_WAVE) {
+                unsigned int m = (n1 - ix0) / DCSG_WAVE;  // whole passes left in this row (ix0 < n1)
+                if (m > DCSG_RUN / DCSG_WAVE - k) m = DCSG_RUN / DCSG_WAVE - k;
+                if (m == 0u) {
+                    pass(k * DCSG_WAVE);
+                    k++;
+                    continue;
+                }
+                const float y = ax[n1 + iy0], z = ax[2u * n1 + plane0];
+                const float* xrow = ax + ix0 + lane;
+#pragma unroll 1
+                for (unsigned int q = 0u; q < m; q++) row_pass(xrow, y, z, q);
+                idx0 += m * DCSG_WAVE;
+                ix0 += m * DCSG_WAVE;
+                if (ix0 >= n1) {  // only when the row length is a multiple of 64
+                    ix0 -= n1;
+                    iy0 += 1u;
+                    if (iy0 == n1) {
+                        iy0 = 0u;
+                        plane0 += 1u;
+                    }
+                }
+                k += m;
+            }
+            continue;
+        }
+#endif
         if (K < 0 && MODE == 1 && left >= DCSG_RUN) {
             // the cheapest kernel (SDF only, per-scene code): four independent passes in flight hide the square root's
             // latency and quarter the loop overhead

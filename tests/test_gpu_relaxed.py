@@ -62,7 +62,9 @@ def test_relaxed_points_and_lattice_close_to_exact(pair, name):
     assert np.abs(sa - sb).max() <= TOL_SDF
     fa, fna = exact.eval_lattice(c, dia, 64)
     fb, fnb = relaxed.eval_lattice(c, dia, 64)
-    assert np.array_equal(fa, sa) and np.array_equal(fb, sb)  # fused and SDF-only kernels agree within a mode
+    # exact mode: the fused and the SDF-only kernel produce the same bits.  Relaxed mode allows FMA contraction, which the
+    # compiler applies per kernel (the fused kernel keeps row-invariant terms in registers): within the tolerance only
+    assert np.array_equal(fa, sa) and np.abs(fb - sb).max() <= TOL_SDF
     ok = np.linalg.norm(fna, axis=3) > 0.5
     assert np.quantile(np.abs(fna - fnb).max(3)[ok], 0.999) <= TOL_NORMAL
 
