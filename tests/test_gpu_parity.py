@@ -584,6 +584,32 @@ def test_normal_all_float_inputs(ev, module):
                     assert bool(same.all()), (hex(c), mixed, k, int((~same).sum()))
 
 
+def test_normal_random_gradients(ev):
+    """normalize's quotients take one residual correction instead of the IEEE sequence's two (DESIGN.md section 3,
+    tools/div_short_probe.hip has the exhaustive mantissa-pair run): 2^30 random gradients of ordinary magnitude through the
+    product kernel against explicitly rounded double arithmetic."""
+    import torch
+    s = read_scene("flat256")
+    assert ev.build(s["scene.txt"], s["buildprocedure.txt"], None)[0] == 0
+    stream = torch.cuda.current_stream().cuda_stream
+    n = 1 << 26
+    out = torch.empty(3 * n, dtype=torch.float32, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rng = np.random.default_rng(12)
+    for it in range(16):
+        # mantissas uniform, exponents spread over 2^-20 .. 2^20
+        x = (torch.rand(n, generator=g, device="cuda") + 1.0) * torch.exp2(torch.randint(-20, 21, (n,), generator=g, device="cuda").float())
+        x = x * (torch.randint(0, 2, (n,), generator=g, device="cuda").float() * 2 - 1)
+        dy, dz = [float(np.float32(rng.uniform(1, 2) * 2.0 ** rng.integers(-20, 21) * rng.choice([-1, 1]))) for _ in range(2)]
+        ev.debug_normal_device(x.data_ptr(), n, dy, dz, 0, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        want = _normal_tail_torch(x, torch.full_like(x, dy), torch.full_like(x, dz))
+        got = out.view(n, 3)
+        for k in range(3):
+            same = want[k].view(torch.int32) == got[:, k].view(torch.int32)
+            assert bool(same.all()), (it, k, int((~same).sum()))
+
+
 def test_set_arbitrary_data_after_build(ev, oracle):
     """Evaluator::setArbitraryData (Evaluator.cpp:213-225) on a loaded scene: the brushes see the new table."""
     s = load(ev, "ad_table")
