@@ -94,7 +94,7 @@ KERNEL_VARIANT = {0: "dcsg_sweep_f", 1: "dcsg_sweep_s4_f", 2: "dcsg_sweep_s8_f",
 SDF_ONLY_KERNEL = {0: "dcsg_sweep_d", 1: "dcsg_sweep_s4_d", 2: "dcsg_sweep_s8_d", 3: "dcsg_sweep_sp_d", 4: "dcsg_sweep_c4"}
 
 
-def time_sweeps(ev, center, diameter, res, reps=10):
+def time_sweeps(ev, center, diameter, res, reps=10, settle_s=0.15):
     """Device time (HIP events on the launch stream) of the fused and of the SDF-only sweep of the whole lattice with the
     scene currently loaded in `ev`.  Secondary lines only: outside the timed region of the headline number."""
     import ctypes as C
@@ -109,10 +109,19 @@ def time_sweeps(ev, center, diameter, res, reps=10):
     out = {}
     for key, nptr in (("fused", nrm.data_ptr()), ("sdf_only", None)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        launch = lambda: L.dcsg_sweep_lattice_device(h, c3, d3, res, 0, n1, C.c_void_p(sdf.data_ptr()), C.c_void_p(nptr) if nptr else None, sp)
+        # untimed lead-in until the clocks have settled (see --settle-s): settle_s seconds of launches, then two more
+        t_end = time.perf_counter() + settle_s
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                rc = launch()
+                if rc:
+                    _lib.check(h, rc)
+            torch.cuda.synchronize()
         for i in range(reps + 2):
             if i == 2:
                 e0.record(stream)
-            rc = L.dcsg_sweep_lattice_device(h, c3, d3, res, 0, n1, C.c_void_p(sdf.data_ptr()), C.c_void_p(nptr) if nptr else None, sp)
+            rc = launch()
             if rc:
                 _lib.check(h, rc)
         e1.record(stream)
@@ -211,6 +220,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle-s", type=float, default=0.3,
+                    help="seconds of untimed steps BEFORE the --warmup steps, so that the GPU has left its idle clock state "
+                         "(a 513^3 sweep takes 0.57 ms on a GPU that was idle 20 ms ago and 0.44 ms once its clocks have "
+                         "settled; W = 5 steps are 3 ms).  Reported as config.settle_steps; 0 disables it")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: sphere512 on one GPU (BASELINE config 2), sphere1024 on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -332,6 +345,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Clock settling (untimed, declared in the output line): the GPU comes out of scene loading idle and needs tens of
+    # milliseconds of work to reach its sustained clocks -- longer than W warm-up steps of a sub-millisecond kernel last.
+    # One process: steps until --settle-s have passed.  Several ranks: a fixed number of steps on every rank (a step holds
+    # a send / receive pair, so all ranks must run the same count).
+    settle_steps = 0
+    if args.settle_s > 0:
+        if world == 1:
+            t_end = time.perf_counter() + args.settle_s
+            while time.perf_counter() < t_end:
+                for _ in range(8):
+                    step()
+                torch.cuda.synchronize()
+                settle_steps += 8
+        else:
+            settle_steps = 64
+            for _ in range(settle_steps):
+                step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -359,8 +389,9 @@ def main():
     if world == 1:
         reps = max(5, args.steps)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for i in range(reps + 2):
-            if i == 2:
+        lead = 2 + (64 if args.settle_s > 0 else 0)   # the timed loop above has just ended: a short lead-in is enough
+        for i in range(reps + lead):
+            if i == lead:
                 e0.record(stream)
             rc = L.dcsg_sweep_lattice_device(h, c3, d3, res, lo, own_hi, C.c_void_p(sdf.data_ptr()), None, sp)
             if rc:
@@ -402,7 +433,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload,
-                       "grid_level": grid_level, "numerics": args.numerics,
+                       "grid_level": grid_level, "numerics": args.numerics, "settle_steps": settle_steps,
                        "parallelism": ("z-slab x%d: %d stacked %d^3-voxel boxes, boundary plane over RCCL" % (world, world, res)
                                        if weak else "z-slab x%d of one %d^3-voxel lattice, halo plane over RCCL" % (world, res)),
                        "lattice_points": (world * res + 1) * plane if weak else n1 ** 3},
