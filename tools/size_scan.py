@@ -1,3 +1,7 @@
+"""Diagnostic: fused sweep time of Z slabs of different heights of the 513^3 sphere lattice, 20 launches each after a
+2-launch lead-in, in one process (run from the repo root on the GPU box).  The first configuration is measured on a GPU
+that has just been idle and is the slow one whatever its size; the list therefore ends with the sizes it began with.
+This is what exposed the clock-settling effect described in DESIGN.md section 6."""
 import ctypes as C, os, sys, json
 sys.path.insert(0, os.getcwd())
 import torch
