@@ -108,7 +108,6 @@ def time_sweeps(ev, center, diameter, res, reps=10, settle_s=0.15):
     c3, d3, sp = (C.c_float * 3)(*center), (C.c_float * 3)(diameter, diameter, diameter), C.c_void_p(stream.cuda_stream)
     out = {}
     for key, nptr in (("fused", nrm.data_ptr()), ("sdf_only", None)):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         launch = lambda: L.dcsg_sweep_lattice_device(h, c3, d3, res, 0, n1, C.c_void_p(sdf.data_ptr()), C.c_void_p(nptr) if nptr else None, sp)
         # untimed lead-in until the clocks have settled (see --settle-s): settle_s seconds of launches, then two more
         t_end = time.perf_counter() + settle_s
@@ -118,15 +117,17 @@ def time_sweeps(ev, center, diameter, res, reps=10, settle_s=0.15):
                 if rc:
                     _lib.check(h, rc)
             torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for i in range(reps + 2):
-            if i == 2:
-                e0.record(stream)
+            if i >= 2:
+                evs[i - 2][0].record(stream)
             rc = launch()
             if rc:
                 _lib.check(h, rc)
-        e1.record(stream)
+            if i >= 2:
+                evs[i - 2][1].record(stream)
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        ms = sum(a.elapsed_time(b) for a, b in evs) / reps   # device time per launch (an event pair around each)
         bytes_ = (16 if nptr else 4) * n1 ** 3
         out[key] = {"kernel_ms": round(ms, 4), "GB_per_s": round(bytes_ / (ms * 1e-3) / 1e9, 1),
                     "frac_of_hbm_peak": round(bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -388,17 +389,18 @@ def main():
     sdf_only = None
     if world == 1:
         reps = max(5, args.steps)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         lead = 2 + (64 if args.settle_s > 0 else 0)   # the timed loop above has just ended: a short lead-in is enough
         for i in range(reps + lead):
-            if i == lead:
-                e0.record(stream)
+            if i >= lead:
+                evs[i - lead][0].record(stream)
             rc = L.dcsg_sweep_lattice_device(h, c3, d3, res, lo, own_hi, C.c_void_p(sdf.data_ptr()), None, sp)
             if rc:
                 _lib.check(h, rc)
-        e1.record(stream)
+            if i >= lead:
+                evs[i - lead][1].record(stream)
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        ms = sum(a.elapsed_time(b) for a, b in evs) / reps   # per launch, as the headline kernel's time above
         gbs = 4 * (own_hi - lo) * plane / (ms * 1e-3) / 1e9
         sdf_only = {"kernel": SDF_ONLY_KERNEL.get(ev.scene_info()["interpreter"], KERNEL_VARIANT[ev.scene_info()["interpreter"]]),
                     "kernel_ms": round(ms, 4), "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
