@@ -486,8 +486,9 @@ def test_jit_of_a_new_brush(ev, oracle, tmp_path):
 
 @pytest.mark.parametrize("module", ["builtin", "scene"])
 def test_sqrt_all_float_inputs(ev, module):
-    """The kernels' square root (fast path for waves whose inputs are all >= 2^-96, the compiler's IEEE sequence
-    otherwise) against IEEE sqrtf for EVERY binary32 bit pattern (builtin module) / every 8th (scene module)."""
+    """The kernels' square root (v_rsq_f32 + one FMA residual correction for waves whose inputs are all ordinary and
+    >= 2^-96, the compiler's IEEE sequence otherwise) against IEEE sqrtf for EVERY binary32 bit pattern (builtin module) /
+    every 8th block of 2^26 (scene module, where the brush prelude's copy is compared with the kernels' as well)."""
     import torch
     if module == "scene":
         load(ev, "design2")
