@@ -351,8 +351,21 @@ def main():
     # One process: steps until --settle-s have passed.  Several ranks: a fixed number of steps on every rank (a step holds
     # a send / receive pair, so all ranks must run the same count).
     settle_steps = 0
+    from_idle = None
     if args.settle_s > 0:
         if world == 1:
+            # for the record: the same W + K procedure on the GPU as scene loading left it (idle clocks), reported next to
+            # the headline as config.from_idle
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            t_i = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt_i = time.perf_counter() - t_i
+            from_idle = {"ms_per_step": round(dt_i / args.steps * 1e3, 4),
+                         "Mvoxels_per_s": round(total_voxels * args.steps / dt_i / 1e6, 2)}
             t_end = time.perf_counter() + args.settle_s
             while time.perf_counter() < t_end:
                 for _ in range(8):
@@ -435,7 +448,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload,
-                       "grid_level": grid_level, "numerics": args.numerics, "settle_steps": settle_steps,
+                       "grid_level": grid_level, "numerics": args.numerics, "settle_steps": settle_steps, "from_idle": from_idle,
                        "parallelism": ("z-slab x%d: %d stacked %d^3-voxel boxes, boundary plane over RCCL" % (world, world, res)
                                        if weak else "z-slab x%d of one %d^3-voxel lattice, halo plane over RCCL" % (world, res)),
                        "lattice_points": (world * res + 1) * plane if weak else n1 ** 3},
