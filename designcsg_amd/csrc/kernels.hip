@@ -76,6 +76,33 @@ __device__ __forceinline__ float dcsg_sqrt(float x)
 }
 #endif
 
+// N square roots with ONE guard: the fast form for all of them, the range tests OR-ed together (scalar unit), one branch.
+// The HIP-native brush bank evaluates the seven stencil points of an object side by side, so this replaces seven
+// compare-and-branch pairs per object by seven compares and one branch and leaves the seven chains free to overlap.
+template <int N>
+__device__ __forceinline__ void dcsg_sqrt_n(const float (&x)[N], float (&r)[N])
+{
+#ifdef DCSG_RELAXED
+#pragma unroll
+    for (int k = 0; k < N; k++) r[k] = dcsg_sqrt(x[k]);
+#else
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        float y = __builtin_amdgcn_rsqf(x[k]);
+        float g = x[k] * y;
+        float h = 0.5f * y;
+        float d = __builtin_fmaf(-g, g, x[k]);
+        r[k] = __builtin_fmaf(d, h, g);
+        bad = bad || !(__float_as_uint(g) - 0x27800000u < 0x58000000u);
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0ull, 0)) {
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = __builtin_sqrtf(x[k]);
+    }
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // wave / block reductions and scans
 // ---------------------------------------------------------------------------
@@ -461,18 +488,27 @@ __device__ __forceinline__ void dcsg_bank_n(const float (&A)[N], const float (&B
 #pragma unroll
         for (int k = 0; k < N; k++) r[k] = (float)K2_MAX_DISTANCE;
         break;
-    case 2:
+    case 2: {
+        float q[N], len[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) r[k] = dcsg_sqrt(A[k] * A[k] + B[k] * B[k] + C[k] * C[k]) - 0.5f;
+        for (int k = 0; k < N; k++) q[k] = A[k] * A[k] + B[k] * B[k] + C[k] * C[k];
+        dcsg_sqrt_n<N>(q, len);
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = len[k] - 0.5f;
         break;
-    case 3:
+    }
+    case 3: {
+        float q[N], rad[N];
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            float ax = __builtin_fabsf(A[k]), ay = __builtin_fabsf(B[k]), az = __builtin_fabsf(C[k]);
-            float rad = dcsg_sqrt(ax * ax + az * az);
-            r[k] = cl_max_f(rad - 0.5f, ay - 0.5f);
+            float ax = __builtin_fabsf(A[k]), az = __builtin_fabsf(C[k]);
+            q[k] = ax * ax + az * az;
         }
+        dcsg_sqrt_n<N>(q, rad);
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = cl_max_f(rad[k] - 0.5f, __builtin_fabsf(B[k]) - 0.5f);
         break;
+    }
     case 4:
 #pragma unroll
         for (int k = 0; k < N; k++) {
