@@ -68,6 +68,7 @@ struct dcsg_ctx {
     Kernels kb, ks;       // built-in bank / scene module
     Kernels* k = nullptr;  // active
     bool scene_loaded = false, jit = false, specialised = false;
+    bool light_scene = false;  // at most four evaluations of standard brushes: its sweeps are store-bound (sweep_grid)
     int numerics = 0;  // DCSG_NUMERICS_EXACT / _RELAXED for the scenes loaded from now on (dcsg_set_numerics)
     bool scene_relaxed = false;
     int variant = 0;  // index into Kernels::sweep[] etc., chosen from the scene's register count
@@ -220,19 +221,29 @@ DcsgLattice make_lattice(const float center[3], const float diam[3], int res)
     return L;
 }
 
-unsigned sweep_grid(const dcsg_ctx* c, unsigned tiles)
+unsigned sweep_grid(const dcsg_ctx* c, unsigned tiles, unsigned tiles_per_block = 0)
 {
-    // 8 resident 256-thread blocks per CU, x8 for tail balance (measured 4..256 per CU on the 1025^3 sweeps: 64 is the
-    // fastest, +5..20 % over 32; one tile per block is 1.5-2.5x slower)
-    static const int per_cu = getenv("DCSG_BLOCKS_PER_CU") ? atoi(getenv("DCSG_BLOCKS_PER_CU")) : 64;
+    // 8 resident 256-thread blocks per CU, x8 for tail balance (measured 4..256 per CU on the 513^3 and 1025^3 sweeps with
+    // settled clocks: 64 is the fastest for the fused kernel at both sizes; one tile per block is 1.5-2.5x slower).
+    // tiles_per_block > 0 (the SDF-only dense sweep of a scene of at most four standard-brush evaluations; a heavy brush
+    // such as Design2's is arithmetic-bound and 2 % slower this way): as many blocks as give each that many tiles, between 64 and 512
+    // per CU.  A block's tiles are `grid` tiles apart, so a launch has as many write fronts moving through the lattice
+    // as a block has tiles; the store-bound SDF-only kernel is fastest with 8 of them at either size (1025^3: 0.89 ms
+    // with 64 blocks per CU = 64 tiles per block, 0.83 / 0.80 / 0.75 ms with 192 / 256 / 512; 513^3, where 64 per CU
+    // already means 8 tiles: 0.110 ms, against 0.139 with 32 per CU and 0.124 with 128), the fused kernel is not.
+    static const int per_cu = getenv("DCSG_BLOCKS_PER_CU") ? atoi(getenv("DCSG_BLOCKS_PER_CU")) : 0;
     unsigned cap = (unsigned)c->n_cu * (unsigned)(per_cu > 0 ? per_cu : 64);
+    if (per_cu <= 0 && tiles_per_block > 0) {
+        unsigned want = tiles / tiles_per_block, hi = (unsigned)c->n_cu * 512u;
+        cap = want < cap ? cap : (want > hi ? hi : want);
+    }
     return tiles < cap ? tiles : cap;
 }
 
 // How a scene's code object is obtained: the stand-alone module with the HIP-native brush bank, or a
 // module compiled from its scene.cl (+ the generated specialisation of its build procedure).
 struct ModulePlan {
-    bool needs_jit = false, specialise = false, null0 = true, relaxed = false;
+    bool needs_jit = false, specialise = false, null0 = true, relaxed = false, light = false;
     std::string cl, extra;
 };
 
@@ -261,6 +272,7 @@ bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std:
     int spec_limit = env_spec ? atoi(env_spec) : 48;
     p.specialise = s.n_stack_prog > 0 && n_evals <= spec_limit && !getenv("DCSG_FORCE_VARIANT");  // A/B runs of the interpreters
     p.needs_jit = !(builtin_only && !p.specialise) || relaxed;  // the relaxed arithmetic exists as a scene module only
+    p.light = builtin_only && n_evals <= 4;
     if (p.needs_jit) {
         if (builtin_only) p.cl = builtin_scene_cl();
         p.null0 = builtin_only || scene_cl_null_brush_is_const(p.cl);
@@ -363,7 +375,7 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
         }
         unsigned tiles = (work + per_block - 1) / per_block;
         void* args[] = {(void*)&blob, &nv, &L, &z0, &first, &cnt, (void*)&d_sdf, (void*)&d_nrm, &axes_off};
-        int r = launch(c, fn, sweep_grid(c, tiles), DCSG_BLOCK, lds, s, args);
+        int r = launch(c, fn, sweep_grid(c, tiles, (d_sdf && !d_nrm && c->light_scene) ? 8u : 0u), DCSG_BLOCK, lds, s, args);
         if (r) return r;
     }
     if (time_it) {
@@ -586,6 +598,7 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
         c->jit = true;
     }
     c->specialised = c->jit && plan.specialise;
+    c->light_scene = plan.light;
     c->scene_relaxed = plan.relaxed;
     // every kernel stages the scene tables in LDS: they must fit one workgroup's share (160 KiB on gfx950)
     if (s.lds_bytes() > 160 * 1024)
