@@ -234,7 +234,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary sweep lines (LDS-table interpreter, "
                     "relaxed numerics, 1024^3)")
     ap.add_argument("--no-export", action="store_true", help="skip the export wall-clock lines (second half of the metric)")
-    ap.add_argument("--verify-halo", action="store_true", help="after the timed loop, check the received halo plane")
+    ap.add_argument("--verify-halo", dest="verify_halo", action="store_true", default=None,
+                    help="after the timed loop (outside the timed region), check the received halo plane against this rank's "
+                         "own evaluation of it; default: on for N > 1")
+    ap.add_argument("--no-verify-halo", dest="verify_halo", action="store_false")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1: strong = the single workload lattice split into N Z slabs (default); "
                          "weak = one workload-sized lattice box per rank, stacked along z")
@@ -262,6 +265,18 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
         else:
             dist.init_process_group("gloo")
+
+    if args.verify_halo is None:
+        args.verify_halo = world > 1
+    # Proof that the communicator really spans N ranks: a sum of ones over the process group, on the
+    # device for nccl (= RCCL), reported as config.rccl_ranks next to the backend torch.distributed says it runs
+    comm = {"backend": None, "ranks_seen": 1}
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        comm = {"backend": dist.get_backend(), "ranks_seen": int(ones.item())}
+        if comm["ranks_seen"] != world:
+            sys.exit("all_reduce over the %s group counted %d ranks, WORLD_SIZE is %d" % (comm["backend"], comm["ranks_seen"], world))
 
     if args.workload is None:
         args.workload = "sphere512" if world == 1 else "sphere1024"
@@ -388,15 +403,25 @@ def main():
         k_ev[i][1].record(stream)
     barrier()
     dt = time.perf_counter() - t0
-    if args.verify_halo and world > 1 and rank < world - 1:
+    halo_ok = None
+    if args.verify_halo and world > 1:
         # the plane received from the upper neighbour must equal what this rank computes for it
-        chk = torch.empty(plane, dtype=torch.float32, device="cuda")
-        chn = torch.empty(3 * plane, dtype=torch.float32, device="cuda")
-        ev.sweep_lattice_device(center, diameter, res, hi, hi + 1, chk.data_ptr(), chn.data_ptr(), stream.cuda_stream)
-        torch.cuda.synchronize()
-        if not (torch.equal(chk.view(torch.int32), halo_sdf.view(torch.int32))
-                and torch.equal(chn.view(torch.int32), halo_nrm.view(torch.int32))):
-            sys.exit("rank %d: halo plane %d differs from the local evaluation" % (rank, hi))
+        bad = torch.zeros(1, dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        if rank < world - 1:
+            chk = torch.empty(plane, dtype=torch.float32, device="cuda")
+            chn = torch.empty(3 * plane, dtype=torch.float32, device="cuda")
+            ev.sweep_lattice_device(center, diameter, res, hi, hi + 1, chk.data_ptr(), chn.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            if not (torch.equal(chk.view(torch.int32), halo_sdf.view(torch.int32))
+                    and torch.equal(chn.view(torch.int32), halo_nrm.view(torch.int32))):
+                sys.stderr.write("rank %d: halo plane %d differs from the local evaluation\n" % (rank, hi))
+                bad += 1
+            del chk, chn
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM)   # every rank learns the verdict (no rank exits alone and hangs the rest)
+        halo_ok = int(bad.item()) == 0
+        if not halo_ok:
+            dist.destroy_process_group()
+            sys.exit("halo verification failed on %d rank(s)" % int(bad.item()))
     # Secondary line (N=1, outside the timed region): the SDF-only sweep of the same lattice -- the 4 B/point
     # kernel the export runs when normals are sampled on demand, and the one BASELINE.json's HBM target names.
     sdf_only = None
@@ -451,7 +476,10 @@ def main():
                        "grid_level": grid_level, "numerics": args.numerics, "settle_steps": settle_steps, "from_idle": from_idle,
                        "parallelism": ("z-slab x%d: %d stacked %d^3-voxel boxes, boundary plane over RCCL" % (world, world, res)
                                        if weak else "z-slab x%d of one %d^3-voxel lattice, halo plane over RCCL" % (world, res)),
-                       "lattice_points": (world * res + 1) * plane if weak else n1 ** 3},
+                       "lattice_points": (world * res + 1) * plane if weak else n1 ** 3,
+                       "comm_backend": comm["backend"], "rccl_ranks": comm["ranks_seen"] if comm["backend"] == "nccl" else None,
+                       "ranks_seen_by_all_reduce": comm["ranks_seen"], "halo_verified": halo_ok},
+            "from_idle": from_idle,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": kernel, "kernel_ms": round(kernel_ms, 4),

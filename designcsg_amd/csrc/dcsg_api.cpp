@@ -8,6 +8,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/vfs.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -58,7 +59,7 @@ thread_local std::string g_create_error;
 struct dcsg_ctx {
     int device = 0;
     int n_cu = 256;
-    size_t max_lds = 65536;
+    size_t max_lds = 160 * 1024;  // LDS one workgroup may request (hipDeviceProp_t::maxSharedMemoryPerMultiProcessor)
     hipStream_t stream = nullptr;
     hipModule_t builtin_mod = nullptr, scene_mod = nullptr;
     DevBuf d_node_mask;                 // node-wise sweep: which nodes of the sweep level hold lattice values
@@ -355,13 +356,13 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     // too large for them (or with rows shorter than a wave) takes the per-lane index path
     size_t lds = (c->scene.lds_bytes() + 15) & ~(size_t)15;
     int axes_off = -1;
-    if (n1 >= DCSG_WAVE && lds + 3 * n1 * sizeof(float) <= 160 * 1024 && c->variant != 4 && !getenv("DCSG_NO_AXIS_TABLES")) {
+    if (n1 >= DCSG_WAVE && lds + 3 * n1 * sizeof(float) <= c->max_lds && c->variant != 4 && !getenv("DCSG_NO_AXIS_TABLES")) {
         axes_off = (int)lds;
         lds += 3 * n1 * sizeof(float);
     }
     // diagnostic: unused LDS per block, to hold fewer blocks on a CU (occupancy experiments, tools/ab_sweep.py)
     static const size_t lds_pad = getenv("DCSG_SWEEP_LDS_PAD") ? (size_t)atol(getenv("DCSG_SWEEP_LDS_PAD")) : 0;
-    if (lds + lds_pad <= 160 * 1024) lds += lds_pad;
+    if (lds + lds_pad <= c->max_lds) lds += lds_pad;
     for (uint64_t p0 = 0; p0 < (uint64_t)(z1 - z0); p0 += planes_per) {
         uint64_t np = (uint64_t)(z1 - z0) - p0 < planes_per ? (uint64_t)(z1 - z0) - p0 : planes_per;
         unsigned first = (unsigned)(p0 * plane);
@@ -424,7 +425,10 @@ int dcsg_create(dcsg_ctx** out, int device_id)
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, device_id));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
+    // dynamic LDS a single workgroup may ask for: the CU's whole LDS on gfx950 (163 840 B); sharedMemPerBlock (64 KiB) is
+    // the static-allocation limit and does not apply to hipModuleLaunchKernel's sharedMemBytes
+    c->max_lds = prop.maxSharedMemoryPerMultiProcessor >= 65536 ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 65536;
+    if (c->max_lds > 160 * 1024) c->max_lds = 160 * 1024;
     lap.mark("hip_runtime_and_device");
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreate(&c->ev0));
@@ -601,10 +605,11 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     c->light_scene = plan.light;
     c->scene_relaxed = plan.relaxed;
     // every kernel stages the scene tables in LDS: they must fit one workgroup's share (160 KiB on gfx950)
-    if (s.lds_bytes() > 160 * 1024)
+    if (s.lds_bytes() > c->max_lds)
         return fail(c, DCSG_ERR_INVALID,
                     "scene tables need " + std::to_string(s.lds_bytes()) + " B of LDS (" + std::to_string(s.n_objects) +
-                        " objects, " + std::to_string(s.n_steps) + " build steps); the limit is 163840 B (about 1400 objects)");
+                        " objects, " + std::to_string(s.n_steps) + " build steps); the limit is " + std::to_string(c->max_lds) +
+                        " B (about 1400 objects at 163840)");
     int r = ensure(c, c->d_blob, s.blob.size() * 4);
     if (r) return r;
     HIPCHK(c, hipMemcpy(c->d_blob.p, s.blob.data(), s.blob.size() * 4, hipMemcpyHostToDevice));
@@ -878,18 +883,24 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             const float* d_list = (const float*)c->d_nodes[cur].p;
             unsigned char* d_mask = (unsigned char*)c->d_node_mask.p;
             int lvl = level, sh = shift;
+            // the slab buffer holds planes z_own_lo .. z_own_hi: nodes of the list that lie outside them (all 64 roots at
+            // level 2, children of parents that straddle slabs) are skipped by the kernel
+            int zo_lo = z_own_lo, zo_hi = z_own_hi;
+            unsigned* d_swept = (unsigned*)((char*)c->d_small.p + 2048);  // zeroed with d_small above
             void* args[] = {(void*)&blob, &nv, &P.lat, (void*)&d_list, &n_nodes, &sh, &lvl, (void*)&ns->d_sdf, (void*)&ns->d_nrm,
-                            (void*)&d_mask, &P.hd[0], &P.hd[1], &P.hd[2]};
+                            (void*)&d_mask, &P.hd[0], &P.hd[1], &P.hd[2], &zo_lo, &zo_hi, (void*)&d_swept};
             HIPCHK(c, hipEventRecord(c->ev0, s));
             if ((r = launch(c, c->k->sweep_nodes[c->variant], n_nodes, DCSG_BLOCK, c->scene.lds_bytes(), s, args))) return r;
             HIPCHK(c, hipEventRecord(c->ev1, s));
-            HIPCHK(c, hipEventSynchronize(c->ev1));
+            unsigned swept = 0;
+            HIPCHK(c, hipMemcpyAsync(&swept, d_swept, sizeof(swept), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
             float ms = 0;
             HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
             ns->ms = ms;
-            ns->nodes = n_nodes;
+            ns->nodes = swept;  // nodes of this slab that the cull rule kept
             const uint64_t side = ((uint64_t)1 << shift) + 1;
-            ns->points = (uint64_t)n_nodes * side * side * side;
+            ns->points = (uint64_t)swept * side * side * side;
             d_sdf = ns->d_sdf;
             d_normals = ns->d_nrm;
             P.z_lo = 0;
@@ -1289,10 +1300,30 @@ struct Mapping {
     void* map = nullptr;
     size_t map_len = 0;
 };
+// File systems on which a successful fallocate(2) means the blocks exist (unwritten extents / resident pages), so that
+// a store into the mapping cannot meet ENOSPC and kill the process with SIGBUS: ext2/3/4, XFS, tmpfs, and overlayfs
+// (which forwards fallocate to such an upper layer on the boxes this runs on).  Anything else -- NFS, FUSE, COW file
+// systems -- takes the pwrite path, where a full disk is an error return.  DCSG_WRITER_MMAP=1 forces the mapping.
+bool fs_honours_fallocate(int fd)
+{
+    if (const char* e = getenv("DCSG_WRITER_MMAP")) return atoi(e) != 0;
+    struct statfs sf;
+    if (fstatfs(fd, &sf) != 0) return false;
+    switch ((unsigned long)sf.f_type) {
+    case 0xEF53ul:      // ext2 / ext3 / ext4
+    case 0x58465342ul:  // XFS
+    case 0x01021994ul:  // tmpfs
+    case 0x794c7630ul:  // overlayfs
+        return true;
+    default:
+        return false;
+    }
+}
+
 Mapping map_range(int fd, off_t off, size_t len, bool reserved)
 {
     Mapping m;
-    if (!reserved || len == 0 || getenv("DCSG_WRITER_NO_MMAP")) return m;
+    if (!reserved || len == 0 || getenv("DCSG_WRITER_NO_MMAP") || !fs_honours_fallocate(fd)) return m;
     const long page = sysconf(_SC_PAGESIZE);
     const off_t lo = off / page * page;
     const size_t span = (size_t)(off - lo) + len;
@@ -1686,11 +1717,40 @@ int export_mesh_stage(dcsg_ctx* c, const dcsg_export_config& cfg, int rank, int 
     // flat256 at 512^3 meshes in 0.8 ms after a 9.5 ms fused sweep instead of 37 ms after a 6 ms SDF sweep.
     const bool dense_normals = (flags & DCSG_EXPORT_DENSE_NORMALS) != 0 ||
                                (c->variant == 4 && !(flags & DCSG_EXPORT_SPARSE_NORMALS));
-    if ((r = ensure(c, c->d_lat_sdf, slab_pts * sizeof(float)))) return r;
-    if (dense_normals && (r = ensure(c, c->d_lat_nrm, slab_pts * 3 * sizeof(float)))) return r;
+    // DCSG_DEBUG_LATTICE_GUARD=<bytes>: diagnostic.  The slab buffers get that many bytes of a known pattern in front and
+    // behind, checked after the sweep and the mesher: a kernel that stores outside the slab's planes fails the export
+    // instead of silently corrupting a neighbouring allocation (tests/test_gpu_fullsize.py runs the slab exports with it).
+    const size_t guard = getenv("DCSG_DEBUG_LATTICE_GUARD") ? ((size_t)atol(getenv("DCSG_DEBUG_LATTICE_GUARD")) + 255) & ~(size_t)255 : 0;
+    if ((r = ensure(c, c->d_lat_sdf, slab_pts * sizeof(float) + 2 * guard))) return r;
+    if (dense_normals && (r = ensure(c, c->d_lat_nrm, slab_pts * 3 * sizeof(float) + 2 * guard))) return r;
+    float* const lat_sdf = (float*)((char*)c->d_lat_sdf.p + guard);
+    float* const lat_nrm = dense_normals ? (float*)((char*)c->d_lat_nrm.p + guard) : nullptr;
+    if (guard) {
+        HIPCHK(c, hipMemsetAsync(c->d_lat_sdf.p, 0xA5, guard, c->stream));
+        HIPCHK(c, hipMemsetAsync((char*)lat_sdf + slab_pts * sizeof(float), 0xA5, guard, c->stream));
+        if (dense_normals) {
+            HIPCHK(c, hipMemsetAsync(c->d_lat_nrm.p, 0xA5, guard, c->stream));
+            HIPCHK(c, hipMemsetAsync((char*)lat_nrm + slab_pts * 3 * sizeof(float), 0xA5, guard, c->stream));
+        }
+    }
+    auto guards_intact = [&]() -> int {
+        if (!guard) return 0;
+        std::vector<unsigned char> h(guard);
+        const void* at[4] = {c->d_lat_sdf.p, (char*)lat_sdf + slab_pts * sizeof(float), dense_normals ? c->d_lat_nrm.p : nullptr,
+                             dense_normals ? (char*)lat_nrm + slab_pts * 3 * sizeof(float) : nullptr};
+        for (int k = 0; k < 4; k++) {
+            if (!at[k]) continue;
+            HIPCHK(c, hipMemcpy(h.data(), at[k], guard, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < guard; i++)
+                if (h[i] != 0xA5)
+                    return fail(c, DCSG_ERR_HIP, std::string("lattice guard overwritten (") + (k & 1 ? "behind" : "in front of") +
+                                                     (k < 2 ? " the SDF slab" : " the normal slab") + ", byte " + std::to_string(i) + ")");
+        }
+        return 0;
+    };
     // the kernels index the lattice by absolute plane: the slab buffer stands for planes z_own_lo .. z_own_hi
-    float* sdf0 = (float*)((uintptr_t)c->d_lat_sdf.p - (uintptr_t)z_own_lo * plane * sizeof(float));
-    float* nrm0 = dense_normals ? (float*)((uintptr_t)c->d_lat_nrm.p - (uintptr_t)z_own_lo * plane * 3 * sizeof(float)) : nullptr;
+    float* sdf0 = (float*)((uintptr_t)lat_sdf - (uintptr_t)z_own_lo * plane * sizeof(float));
+    float* nrm0 = dense_normals ? (float*)((uintptr_t)lat_nrm - (uintptr_t)z_own_lo * plane * 3 * sizeof(float)) : nullptr;
     float diam3[3] = {diameter, diameter, diameter};
     // Node-wise sweep (default): the mesher's first levels sample on demand; at level max(min,2) -- the first whose
     // nodes the cull rule can drop for good -- the lattice is evaluated inside the nodes that are still alive, which
@@ -1709,9 +1769,8 @@ int export_mesh_stage(dcsg_ctx* c, const dcsg_export_config& cfg, int rank, int 
         if ((r = mesh_impl(c, st.box_center, diameter, &cfg, nullptr, nullptr, 0, res, z_own_lo, z_own_hi, &n_tris, &st.mesh, c->stream, &ns)))
             return r;
         st.sweep_kernel_ms = ns.ms;
-        // candidates the cull rule dropped are not swept; they are exactly the nodes counted as culled at that level
-        st.swept_nodes = ns.nodes - st.mesh.culled[ns.level];
-        st.swept_points = ns.nodes ? ns.points / ns.nodes * st.swept_nodes : 0;
+        st.swept_nodes = ns.nodes;
+        st.swept_points = ns.points;
         st.t_sweep = ns.ms * 1e-3;
         st.t_mesh = now_s() - t0 - st.t_sweep;
     } else {
@@ -1734,13 +1793,16 @@ int export_mesh_stage(dcsg_ctx* c, const dcsg_export_config& cfg, int rank, int 
 
         // mesher (retopologize = identity: the reference's is undefined behaviour)
         t0 = now_s();
-        if ((r = dcsg_mesh_lattice_device(c, st.box_center, diameter, &cfg, (const float*)c->d_lat_sdf.p,
-                                          dense_normals ? (const float*)c->d_lat_nrm.p : nullptr, z_own_lo, z_own_hi, z_own_lo,
+        if ((r = dcsg_mesh_lattice_device(c, st.box_center, diameter, &cfg, lat_sdf, lat_nrm, z_own_lo, z_own_hi, z_own_lo,
                                           z_own_hi, &n_tris, &st.mesh, c->stream)))
             return r;
         st.t_mesh = now_s() - t0;
     }
+    if ((r = guards_intact())) return r;
     if (flags & DCSG_EXPORT_RETOPO) {  // opt-in; the default reproduces the reference's (repaired) identity
+        // the repair looks up the mesh vertex occupying a cell: a slab only sees its own vertices, so T-junctions on slab
+        // borders would stay open and the result would differ from the single-GPU mesh
+        if (world > 1) return fail(c, DCSG_ERR_INVALID, "DCSG_EXPORT_RETOPO is not available for Z-slab exports (world > 1)");
         if ((r = dcsg_retopologize(c, st.box_center, diameter, cfg.min_level, cfg.grid_level, c->stream))) return r;
         n_tris = c->n_tris;
     }

@@ -1251,6 +1251,15 @@ __device__ __forceinline__ bool dcsg_node_culled(float d, float hx, float hy, fl
     return __builtin_fabsf(d) > mag * 1.1f;
 }
 
+// Z-slab exports (dcsg_export_slab): the level's node list also holds nodes outside this rank's slab -- all 64 roots at
+// level 2, every child of a parent that straddles slabs -- and the slab buffer holds planes z_own_lo .. z_own_hi only.
+// A node whose planes [i0z, i0z + 2^shift] do not lie inside the slab is not swept: nothing is stored for it and its
+// mask byte stays 0 (the mesher classifies such a node as "outside this rank" before it samples anything).
+__device__ __forceinline__ bool dcsg_node_outside_slab(int i0z, int shift, int z_own_lo, int z_own_hi)
+{
+    return i0z < z_own_lo || i0z + (1 << shift) > z_own_hi;
+}
+
 // Local point index p of a node block -> (lx, ly, lz), p = (lz*side + ly)*side + lx, without integer division:
 // side = 2^shift + 1 <= 33 and p < side^3 < 2^16, for which floor(p * (floor(2^32/d) + 1) / 2^32) = p / d exactly.
 struct DcsgNodeGrid {
@@ -1289,7 +1298,8 @@ template <int K>
 __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ blob, int n_vec4, const DcsgLattice& L,
                                                       const float* __restrict__ nodes, unsigned int n_nodes, int shift, int level,
                                                       float* __restrict__ sdf_out, float* __restrict__ nrm_out,
-                                                      unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz)
+                                                      unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz,
+                                                      int z_own_lo, int z_own_hi, unsigned int* __restrict__ n_swept)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     __shared__ float tab[3 * DCSG_NODE_TAB];
@@ -1299,6 +1309,7 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
         int i0[3], ic[3];
         size_t slot;
         dcsg_node_origin(L, nodes, n, shift, level, i0, ic, slot);
+        if (dcsg_node_outside_slab(i0[2], shift, z_own_lo, z_own_hi)) continue;
         {   // every lane evaluates the same point: uniform, no divergence
             float cx = dcsg_lattice_coord(L, 0, ic[0]), cy = dcsg_lattice_coord(L, 1, ic[1]), cz = dcsg_lattice_coord(L, 2, ic[2]);
             float d, u0, u1, u2;
@@ -1309,7 +1320,10 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
             else dcsg_stencil<(K <= 0 ? 4 : K)>(s, cx, cy, cz, true, false, d, u0, u1, u2);
             if (dcsg_node_culled(d, hdx, hdy, hdz)) continue;
         }
-        if (threadIdx.x == 0) node_mask[slot] = 1;
+        if (threadIdx.x == 0) {
+            node_mask[slot] = 1;
+            atomicAdd(n_swept, 1u);
+        }
         dcsg_node_axes(L, i0, g.side, tab);
         const size_t base = ((size_t)i0[2] * n1 + (size_t)i0[1]) * n1 + (size_t)i0[0];
         for (unsigned int p = threadIdx.x; p < g.pts; p += DCSG_BLOCK) {
@@ -1343,10 +1357,11 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
     extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                         \
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,                 \
          unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,       \
-         unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz)                                     \
+         unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz, int z_own_lo, int z_own_hi,        \
+         unsigned int* __restrict__ n_swept)                                                                         \
     {                                                                                                                \
         dcsg_sweep_nodes_body<K>(blob, n_vec4, L, nodes, n_nodes, shift, level, sdf_out, nrm_out, node_mask, hdx,    \
-                                 hdy, hdz);                                                                          \
+                                 hdy, hdz, z_own_lo, z_own_hi, n_swept);                                             \
     }
 #ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes, 0)
@@ -2103,7 +2118,8 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,
                     unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,
-                    unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz)
+                    unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz, int z_own_lo, int z_own_hi,
+                    unsigned int* __restrict__ n_swept)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     __shared__ float tab[3 * DCSG_NODE_TAB];
@@ -2115,6 +2131,7 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
         int i0[3], ic[3];
         size_t slot;
         dcsg_node_origin(L, nodes, n, shift, level, i0, ic, slot);
+        if (dcsg_node_outside_slab(i0[2], shift, z_own_lo, z_own_hi)) continue;  // block-uniform
         float lo[3], hi[3];
         for (int k = 0; k < 3; k++) {
             lo[k] = dcsg_lattice_coord(L, k, i0[k]);
@@ -2131,7 +2148,10 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
                             true, false, d, u0, u1, u2, list, n_list);
             if (dcsg_node_culled(d, hdx, hdy, hdz)) continue;
         }
-        if (threadIdx.x == 0) node_mask[slot] = 1;
+        if (threadIdx.x == 0) {
+            node_mask[slot] = 1;
+            atomicAdd(n_swept, 1u);
+        }
         dcsg_node_axes(L, i0, side, tab);
         const size_t base = ((size_t)i0[2] * n1 + (size_t)i0[1]) * n1 + (size_t)i0[0];
         for (unsigned int p0 = 0; p0 < pts; p0 += DCSG_BLOCK) {

@@ -6,7 +6,10 @@
 import numpy as np
 
 
-def make_script(seed, big=False):
+def make_script(seed, big=False, smooth=True):
+    """smooth=False: only what the reference's own API knows (no smooth joins), plus its remaining helpers -- draw_box,
+    drawComponent / eraseComponent over a prefab with children, apply_transform -- for the front-end corpus
+    (tests/golden/make_frontend_corpus.py runs these scripts on the reference Python)."""
     rng = np.random.default_rng(seed)
     L = ["from DesignCSG import *", "from designlibrary import *", "import numpy as np", "import scenecompiler", ""]
     brushes = ["sphere_brush", "box_brush", "cylinder_brush"]
@@ -39,14 +42,29 @@ def make_script(seed, big=False):
             fn = ["drawUnion", "eraseUnion", "drawIntersection", "eraseIntersection"][rng.integers(4)]
             kids = ", ".join(leaf() for _ in range(int(rng.integers(2, 10 if big else 5))))
             L.append("%s(%s, transform=%s)" % (fn, kids, tf()))
+        elif kind <= 8 and not smooth:
+            which = rng.integers(3)
+            if which == 0:
+                L.append("draw_box(np.array(%r), %r)" % (list(np.round(rng.uniform(-0.6, 0.6, 3), 3)), float(np.round(rng.uniform(0.1, 0.7), 3))))
+            else:   # a prefab with children, instantiated under a transform (fabricate), once moved afterwards
+                L.append("pf = %s" % leaf())
+                for _ in range(int(rng.integers(1, 4))):
+                    L.append("pf.add_child(%s)" % leaf())
+                if rng.random() < 0.5:
+                    L.append("pf.apply_transform(%s)" % tf())
+                L.append("%s(pf, transform=%s)" % ("drawComponent" if which == 1 else "eraseComponent", tf()))
         elif kind <= 8:
             fn = ["drawSmoothUnion", "eraseSmoothUnion", "drawSmoothIntersection", "eraseSmoothIntersection"][rng.integers(4)]
             kids = ", ".join(leaf() for _ in range(int(rng.integers(2, 10 if big else 5))))
             L.append("%s(%s, k=%r, transform=%s)" % (fn, kids, float(np.round(rng.uniform(0.02, 0.3), 3)), tf()))
         else:   # hand-built nesting: a smooth or hard group holding a carved leaf and an inner group
-            outer = ("scenecompiler.SmoothComponent(%r, brush=compiler.null_brush(), material=compiler.default_material(), "
-                     "transform=%s)" % (float(np.round(rng.uniform(0.03, 0.2), 3)), tf())) if rng.random() < 0.5 else \
-                ("scenecompiler.Component(brush=compiler.null_brush(), material=compiler.default_material(), transform=%s)" % tf())
+            if smooth:
+                outer = ("scenecompiler.SmoothComponent(%r, brush=compiler.null_brush(), material=compiler.default_material(), "
+                         "transform=%s)" % (float(np.round(rng.uniform(0.03, 0.2), 3)), tf())) if rng.random() < 0.5 else \
+                    ("scenecompiler.Component(brush=compiler.null_brush(), material=compiler.default_material(), transform=%s)" % tf())
+            else:   # a hard group or an intersection group, drawn or carved
+                outer = "scenecompiler.%s(brush=compiler.null_brush(), material=compiler.default_material(), transform=%s%s)" % (
+                    "IntersectionComponent" if rng.random() < 0.4 else "Component", tf(), ", subtractive=True" if rng.random() < 0.3 else "")
             L.append("g = " + outer)
             L.append("g.add_child(%s)" % leaf())
             L.append("g.add_child(scenecompiler.Component(brush=%s, material=compiler.default_material(), transform=%s, "

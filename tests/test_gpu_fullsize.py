@@ -192,6 +192,42 @@ def test_slab_exports_write_the_whole_mesh_into_one_file(ev, name, levels, world
     assert np.array_equal(pf, np.arange(3 * total, dtype=np.uint32).reshape(-1, 3))
 
 
+@pytest.mark.parametrize("name,levels,world", [("design2", (2, 5, 6), 2), ("design2", (2, 5, 6), 4), ("design2", (3, 5, 7), 8),
+                                               ("flat256", (2, 5, 6), 4), ("sphere", (3, 6, 7), 8)])
+def test_slab_exports_stay_inside_their_slab_buffers(built_lib, name, levels, world, monkeypatch):
+    """Low minimum levels: the node list of the sweep level holds nodes outside the rank's slab (all 64 roots at level 2,
+    every child of a parent that straddles slabs at level 3 with 8 slabs).  On a FRESH context -- one that never held
+    the whole lattice, so its buffers are slab-sized -- with guard bands around the slab buffers
+    (DCSG_DEBUG_LATTICE_GUARD): the node-wise sweep must leave the guards untouched (the export fails otherwise) and the
+    slabs must add up to the single-GPU mesh."""
+    from designcsg_amd.evaluator import Evaluator
+    s = read_scene(name)
+    cfg_txt = export_config_text(name, levels=list(levels), gd=4)
+    whole_ev = Evaluator(0)
+    try:
+        assert whole_ev.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
+        whole = whole_ev.export(cfg_txt)
+        want = tri_set_hash(whole_ev.download_triangles())
+    finally:
+        whole_ev.close()
+    monkeypatch.setenv("DCSG_DEBUG_LATTICE_GUARD", str(8 << 20))
+    parts, stats = [], []
+    for r in range(world):
+        e = Evaluator(0)   # fresh: buffers sized by this slab alone
+        try:
+            assert e.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
+            st = e.export_slab(cfg_txt, r, world)
+            stats.append(st)
+            parts.append(e.download_triangles().reshape(-1, 9))
+        finally:
+            e.close()
+    assert sum(int(st.triangles) for st in stats) == whole.triangles
+    assert tri_set_hash(np.concatenate(parts)) == want
+    if (1 << max(levels[0], 2)) >= world:   # node-wise on every rank: each sweeps its own nodes only
+        assert all(int(st.swept_nodes) > 0 or int(st.triangles) == 0 for st in stats)
+        assert sum(int(st.swept_nodes) for st in stats) == whole.swept_nodes
+
+
 def test_export_multi_through_the_c_boundary(ev, tmp_path):
     """dcsg_export_multi: n contexts in one process (here all on this GPU; one per GPU on a node), one host thread and
     one Z slab each, per-slab byte ranges of the two files.  The files hold the single-context export's triangle set."""
