@@ -1,8 +1,9 @@
 """Builds every native artefact of designcsg_amd for gfx950, in-tree under designcsg_amd/_build/.
 
   dcsg_builtin.hsaco        kernels.hip with the HIP-native built-in brush bank (code object)
-  dcsg_kernels_{spec,interp}.bc          kernels.hip as device bitcode, linked against a scene.cl at load time
-  dcsg_kernels_relaxed_{spec,interp}.bc  the same with the opt-in relaxed arithmetic (dcsg_set_numerics)
+  dcsg_kernels_{spec,interp}_{export,rest}.bc          kernels.hip as device bitcode (two kernel sets, each in two
+                                                       parts), linked against a scene.cl at load time
+  dcsg_kernels_relaxed_{spec,interp}_{export,rest}.bc  the same with the opt-in relaxed arithmetic (dcsg_set_numerics)
   libdcsg_hip.so            the C ABI (include/dcsg.h): host side + comgr JIT
   jitcache/*.hsaco          per-scene code objects compiled ahead of time (optional warm-up)
 
@@ -25,6 +26,8 @@ ARCH = "gfx950"
 # -fno-slp-vectorize: packed-f32 VALU ops are slower than the scalar pairs they replace on gfx950
 DEVICE_FLAGS = ["--offload-arch=" + ARCH, "--cuda-device-only", "-O3", "-ffp-contract=off", "-fno-slp-vectorize",
                 "-std=c++17"]
+# A/B builds only (tools/ab_sweep.py on a copy of the tree): extra defines for kernels.hip, e.g. DCSG_BUILD_DEFS="-DDCSG_NO_NT_STORES"
+DEVICE_FLAGS += [f for f in os.environ.get("DCSG_BUILD_DEFS", "").split() if f]
 LIB = os.path.join(OUT, "libdcsg_hip.so")
 RELAXED_SCENES = ("sphere", "design2", "design1")
 
@@ -67,20 +70,23 @@ def build(verbose=False, prebuild_scenes=True):
     # interpreters + mesher + preview); each also with the opt-in relaxed arithmetic (dcsg_set_numerics).
     rebuilt = False
     relaxed_flags = [f for f in DEVICE_FLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast"]
-    for name, flags, defs in (("dcsg_kernels_spec.bc", DEVICE_FLAGS, ["-DDCSG_SET_SPEC"]),
-                              ("dcsg_kernels_interp.bc", DEVICE_FLAGS, ["-DDCSG_SET_INTERP"]),
-                              ("dcsg_kernels_relaxed_spec.bc", relaxed_flags, ["-DDCSG_SET_SPEC", "-DDCSG_RELAXED"]),
-                              ("dcsg_kernels_relaxed_interp.bc", relaxed_flags, ["-DDCSG_SET_INTERP", "-DDCSG_RELAXED"])):
-        bc = os.path.join(OUT, name)
-        if _newer(bc, dev_deps):
-            _run([HIPCC] + flags + ["-fgpu-rdc", "-emit-llvm", "-DDCSG_EXTERN_BANK"] + defs + ["-c", kernels, "-o", bc])
-            rebuilt = True
+    # ... and each set in two parts, so that a cold JIT compiles first what an export launches (csrc/jit.cpp): "export"
+    # (stage A, node-wise sweep, mesher, projection, de-duplication) and "rest" (dense sweeps, point evaluation,
+    # T-junction repair, test kernels, preview).
+    for set_name, set_def in (("spec", "-DDCSG_SET_SPEC"), ("interp", "-DDCSG_SET_INTERP")):
+        for part, part_def in (("export", "-DDCSG_PART_EXPORT"), ("rest", "-DDCSG_PART_REST")):
+            for prefix, flags, extra in (("dcsg_kernels_", DEVICE_FLAGS, []), ("dcsg_kernels_relaxed_", relaxed_flags, ["-DDCSG_RELAXED"])):
+                bc = os.path.join(OUT, prefix + set_name + "_" + part + ".bc")
+                if _newer(bc, dev_deps):
+                    _run([HIPCC] + flags + ["-fgpu-rdc", "-emit-llvm", "-DDCSG_EXTERN_BANK", set_def, part_def] + extra + ["-c", kernels, "-o", bc])
+                    rebuilt = True
     if rebuilt:
         # every cached scene module was linked against the old kernel bitcode (its hash is part of the key):
         # drop them so that stale code objects do not pile up (the fixture scenes are rebuilt below)
         for f in glob.glob(os.path.join(OUT, "jitcache", "*.hsaco")):
             os.remove(f)
-    for stale in ("dcsg_kernels_extern.bc", "dcsg_kernels_relaxed.bc"):
+    for stale in ("dcsg_kernels_extern.bc", "dcsg_kernels_relaxed.bc", "dcsg_kernels_spec.bc", "dcsg_kernels_interp.bc",
+                  "dcsg_kernels_relaxed_spec.bc", "dcsg_kernels_relaxed_interp.bc"):
         if os.path.exists(os.path.join(OUT, stale)):
             os.remove(os.path.join(OUT, stale))
 

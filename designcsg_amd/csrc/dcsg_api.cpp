@@ -41,6 +41,7 @@ struct DevBuf {
 struct Kernels {
     hipFunction_t sweep[5] = {}, eval_points[5] = {}, bbox[5] = {}, project[5] = {};
     hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr, test_normal = nullptr;
+    hipFunction_t set_ad_rest = nullptr;  // the rest part of a scene module has its own `arbitrary_data` pointer
     hipFunction_t sweep_d[4] = {}, sweep_f[4] = {};  // sweep[v] with the outputs fixed at compile time: SDF only / SDF + normals
     hipFunction_t sweep_nodes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // node-wise sweep per variant
     hipFunction_t dd_insert = nullptr, dd_resolve = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
@@ -62,6 +63,17 @@ struct dcsg_ctx {
     size_t max_lds = 160 * 1024;  // LDS one workgroup may request (hipDeviceProp_t::maxSharedMemoryPerMultiProcessor)
     hipStream_t stream = nullptr;
     hipModule_t builtin_mod = nullptr, scene_mod = nullptr;
+    // A scene module comes in two code objects (jit.hpp): scene_mod = the export part, loaded by dcsg_load_scene;
+    // scene_mod_rest = dense sweeps, point evaluation, T-junction repair, test kernels -- loaded on first use
+    // (need_rest).  After a cold build of the export part the rest is compiled by a background host thread (comgr only,
+    // no HIP call) while the caller already exports.
+    hipModule_t scene_mod_rest = nullptr;
+    std::thread rest_thread;
+    bool rest_wanted = false;   // the loaded scene has a rest part that is not loaded yet
+    bool rest_thread_ok = false;
+    int rest_kind = 0;
+    std::string rest_cl, rest_extra, rest_hsaco, rest_log;
+    bool rest_relaxed = false, rest_spec = false;
     DevBuf d_node_mask;                 // node-wise sweep: which nodes of the sweep level hold lattice values
     hipModule_t preview_mod = nullptr;  // scene.cl as given + kernels, built on the first dcsg_render_preview of a scene
     hipFunction_t preview_fn = nullptr;
@@ -70,6 +82,7 @@ struct dcsg_ctx {
     Kernels* k = nullptr;  // active
     bool scene_loaded = false, jit = false, specialised = false;
     bool light_scene = false;  // at most four evaluations of standard brushes: its sweeps are store-bound (sweep_grid)
+    bool row_kernels = false;  // the scene module holds dcsg_spec_row4*: dense sweeps may take dcsg_sweep_rows
     int numerics = 0;  // DCSG_NUMERICS_EXACT / _RELAXED for the scenes loaded from now on (dcsg_set_numerics)
     bool scene_relaxed = false;
     int variant = 0;  // index into Kernels::sweep[] etc., chosen from the scene's register count
@@ -155,31 +168,41 @@ void release(DevBuf& b)
 
 // kind: 0 the stand-alone module (interpreters + culling kernels), 1 a scene module of the "spec" set (per-scene
 // specialised kernels only), 2 a scene module of the "interp" set (interpreters) -- designcsg_amd/build.py
-int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind)
+// part: 0 = both parts from one module (the stand-alone code object), 1 = the export part of a scene module
+// (stage A, node-wise sweep, mesher, projection, de-duplication), 2 = its rest part (dense sweeps, point evaluation,
+// T-junction repair, test kernels) -- kernels.hip, DCSG_PART_*.  Entries of the other part are left as they are.
+int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind, int part = 0)
 {
     static const char* suffix[4] = {"", "_s4", "_s8", "_sp"};
-    k = Kernels();
+    const bool exp = part != 2, rest = part != 1;
+    if (part != 2) k = Kernels();
     for (int v = (kind == 1 ? 3 : 0); v < (kind == 1 ? 4 : 3); v++) {
         struct {
             const char* name;
             hipFunction_t* f;
-        } tab[] = {{"dcsg_sweep", &k.sweep[v]}, {"dcsg_eval_points", &k.eval_points[v]}, {"dcsg_bbox", &k.bbox[v]},
-                   {"dcsg_project", &k.project[v]}, {"dcsg_sweep_nodes", &k.sweep_nodes[v]}};
-        for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, (std::string(t.name) + suffix[v]).c_str()));
-        HIPCHK(c, hipModuleGetFunction(&k.sweep_d[v], mod, (std::string("dcsg_sweep") + suffix[v] + "_d").c_str()));
-        HIPCHK(c, hipModuleGetFunction(&k.sweep_f[v], mod, (std::string("dcsg_sweep") + suffix[v] + "_f").c_str()));
+            bool in_export;
+        } tab[] = {{"dcsg_sweep", &k.sweep[v], false}, {"dcsg_eval_points", &k.eval_points[v], false}, {"dcsg_bbox", &k.bbox[v], true},
+                   {"dcsg_project", &k.project[v], true}, {"dcsg_sweep_nodes", &k.sweep_nodes[v], true}};
+        for (auto& t : tab)
+            if (t.in_export ? exp : rest) HIPCHK(c, hipModuleGetFunction(t.f, mod, (std::string(t.name) + suffix[v]).c_str()));
+        if (rest) {
+            HIPCHK(c, hipModuleGetFunction(&k.sweep_d[v], mod, (std::string("dcsg_sweep") + suffix[v] + "_d").c_str()));
+            HIPCHK(c, hipModuleGetFunction(&k.sweep_f[v], mod, (std::string("dcsg_sweep") + suffix[v] + "_f").c_str()));
+        }
     }
     struct {
         const char* name;
         hipFunction_t* f;
-    } tab[] = {{"dcsg_mesh_classify", &k.classify}, {"dcsg_scan_blocks", &k.scan}, {"dcsg_mesh_emit", &k.emit},
-               {"dcsg_test_sqrt", &k.test_sqrt},       {"dcsg_dedup_insert", &k.dd_insert},
-               {"dcsg_test_normal", &k.test_normal},
-               {"dcsg_dedup_count", &k.dd_count},      {"dcsg_dedup_gather", &k.dd_gather},
-               {"dcsg_dedup_scatter", &k.dd_scatter},  {"dcsg_dedup_resolve", &k.dd_resolve},
-               {"dcsg_retopo_mark", &k.rt_mark},
-               {"dcsg_retopo_count", &k.rt_count},     {"dcsg_retopo_emit", &k.rt_emit}};
-    for (auto& t : tab) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
+        bool in_export;
+    } tab[] = {{"dcsg_mesh_classify", &k.classify, true}, {"dcsg_scan_blocks", &k.scan, true}, {"dcsg_mesh_emit", &k.emit, true},
+               {"dcsg_test_sqrt", &k.test_sqrt, false},       {"dcsg_dedup_insert", &k.dd_insert, true},
+               {"dcsg_test_normal", &k.test_normal, false},
+               {"dcsg_dedup_count", &k.dd_count, true},      {"dcsg_dedup_gather", &k.dd_gather, true},
+               {"dcsg_dedup_scatter", &k.dd_scatter, true},  {"dcsg_dedup_resolve", &k.dd_resolve, true},
+               {"dcsg_retopo_mark", &k.rt_mark, false},
+               {"dcsg_retopo_count", &k.rt_count, false},     {"dcsg_retopo_emit", &k.rt_emit, false}};
+    for (auto& t : tab)
+        if (t.in_export ? exp : rest) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
     if (kind == 0) {
         HIPCHK(c, hipModuleGetFunction(&k.sweep[4], mod, "dcsg_sweep_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.sweep_nodes[4], mod, "dcsg_sweep_nodes_c4"));
@@ -187,7 +210,7 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind)
         HIPCHK(c, hipModuleGetFunction(&k.project[4], mod, "dcsg_project_c4"));
         k.eval_points[4] = k.eval_points[1];  // arbitrary points have no spatial coherence to exploit
     } else {
-        HIPCHK(c, hipModuleGetFunction(&k.set_ad, mod, "dcsg_set_arbitrary_data"));
+        HIPCHK(c, hipModuleGetFunction(part == 2 ? &k.set_ad_rest : &k.set_ad, mod, "dcsg_set_arbitrary_data"));
     }
     return 0;
 }
@@ -245,6 +268,7 @@ unsigned sweep_grid(const dcsg_ctx* c, unsigned tiles, unsigned tiles_per_block 
 // module compiled from its scene.cl (+ the generated specialisation of its build procedure).
 struct ModulePlan {
     bool needs_jit = false, specialise = false, null0 = true, relaxed = false, light = false;
+    bool rows = false;  // the module holds the row kernels' evaluation (dense sweeps of store-bound scenes)
     std::string cl, extra;
 };
 
@@ -277,7 +301,7 @@ bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std:
     if (p.needs_jit) {
         if (builtin_only) p.cl = builtin_scene_cl();
         p.null0 = builtin_only || scene_cl_null_brush_is_const(p.cl);
-        p.extra = specialised_source(s, p.null0, p.specialise, builtin_only && !getenv("DCSG_NO_SIMPLIFY"));
+        p.extra = specialised_source(s, p.null0, p.specialise, builtin_only && !getenv("DCSG_NO_SIMPLIFY"), &p.rows);
     }
     return true;
 }
@@ -291,8 +315,41 @@ int need_scene(dcsg_ctx* c)
     return 0;
 }
 
+// Ends the background build of the rest part, if one is running (the result stays in c->rest_hsaco).
+void join_rest_thread(dcsg_ctx* c)
+{
+    if (c->rest_thread.joinable()) c->rest_thread.join();
+}
+
+// Makes the rest part of the scene module available: dense sweeps, point evaluation, T-junction repair, test kernels.
+// Loaded on first use -- from the JIT cache, from the background build a cold dcsg_load_scene started, or compiled here.
+int need_rest(dcsg_ctx* c)
+{
+    if (!c->jit || !c->rest_wanted) return 0;
+    join_rest_thread(c);
+    if (c->rest_hsaco.empty() || !c->rest_thread_ok) {
+        bool cached = false;
+        c->rest_log.clear();
+        if (!jit_scene_module(c->rest_cl, c->rest_extra, c->rest_hsaco, c->rest_log, &cached, c->rest_relaxed, c->rest_spec, JIT_PART_REST))
+            return fail(c, DCSG_ERR_BUILD, "Error when building evaluation program:\n" + c->rest_log);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipModuleLoadData(&c->scene_mod_rest, c->rest_hsaco.data()));
+    int r = load_kernels(c, c->scene_mod_rest, c->ks, c->rest_kind, 2);
+    if (r) return r;
+    void* adp = c->d_ad.p;
+    void* args[] = {&adp};
+    if ((r = launch(c, c->ks.set_ad_rest, 1, 64, 0, c->stream, args))) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // other streams may launch this module's kernels next
+    c->rest_wanted = false;
+    c->rest_hsaco.clear();
+    c->rest_hsaco.shrink_to_fit();
+    return 0;
+}
+
 int eval_points_device(dcsg_ctx* c, const float* d_xyz, size_t n, int mode, float* d_out, hipStream_t s)
 {
+    if (int rr = need_rest(c)) return rr;
     const size_t chunk = 256u * 256u * 256u;  // MAX_EVAL_POINTS, Evaluator.h:16
     const void* blob = c->d_blob.p;
     int nv = c->scene.blob_vec4();
@@ -334,6 +391,7 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
 {
     if (res < 1 || z0 < 0 || z1 > res + 1 || z0 > z1) return fail(c, DCSG_ERR_INVALID, "bad lattice range");
     if (!d_sdf && !d_nrm) return 0;
+    if (int rr = need_rest(c)) return rr;
     for (int k = 0; k < 3; k++)  // lattice coordinates stay finite (the specialised kernels rely on it)
         if (!(std::fabs(center[k]) <= 1e29f) || !(std::fabs(diam[k]) <= 1e29f))
             return fail(c, DCSG_ERR_INVALID, "lattice box is not finite");
@@ -345,9 +403,10 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     const void* blob = c->d_blob.p;
     int nv = c->scene.blob_vec4();
     if (time_it) HIPCHK(c, hipEventRecord(c->ev0, s));
-    // launches cover whole planes, < 2^30 points each
+    // launches cover whole planes, < 2^32 points each (the kernels' flat indices are 32-bit, byte offsets 64-bit): the
+    // 1025^3 lattice is one launch (rounds 1-2: 2^30 points, i.e. 1022 planes and a 3-plane tail launch)
     const uint64_t plane = n1 * n1;
-    uint64_t planes_per = (1ull << 30) / plane;
+    uint64_t planes_per = 0xf0000000ull / plane;
     planes_per = planes_per < 1 ? 1 : planes_per;
     // kernels with the outputs fixed at compile time where they exist (SDF only / SDF + normals)
     hipFunction_t fn = c->k->sweep[c->variant];
@@ -360,6 +419,26 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
         axes_off = (int)lds;
         lds += 3 * n1 * sizeof(float);
     }
+    // Several points per lane with shared unperturbed stencil coordinates (kernels.hip: dcsg_run4 for store-bound scenes,
+    // the multi-pass interpretation of the stack interpreters): needs the axis tables and a lattice without a -0.0
+    // coordinate (checked here with the kernels' arithmetic, dcsg_lattice_coord, in the same IEEE operations: this file
+    // is built with -ffp-contract=off).
+    unsigned flags = 0;
+    if (c->variant < 4 && d_sdf && axes_off >= 0 && !getenv("DCSG_NO_ROWS")) {
+        bool neg_zero = false;
+        for (int k = 0; k < 3 && !neg_zero; k++)
+            for (uint64_t i = 0; i < n1 && !neg_zero; i++) {
+                volatile float t = L.diam[k] * (float)(int)i;
+                volatile float u = L.w_pow2 ? t * L.inv_w : t / L.w;
+                volatile float v = L.base[k] + u;
+                float vv = v;
+                uint32_t b;
+                memcpy(&b, &vv, 4);
+                neg_zero = b == 0x80000000u;
+            }
+        if (!neg_zero) flags |= DCSG_SWEEP_ROWS;
+    }
+    if (!getenv("DCSG_NO_MULTIPASS")) flags |= DCSG_SWEEP_MULTIPASS;
     // diagnostic: unused LDS per block, to hold fewer blocks on a CU (occupancy experiments, tools/ab_sweep.py)
     static const size_t lds_pad = getenv("DCSG_SWEEP_LDS_PAD") ? (size_t)atol(getenv("DCSG_SWEEP_LDS_PAD")) : 0;
     if (lds + lds_pad <= c->max_lds) lds += lds_pad;
@@ -375,8 +454,9 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
             per_block = DCSG_BLOCK;
         }
         unsigned tiles = (work + per_block - 1) / per_block;
-        void* args[] = {(void*)&blob, &nv, &L, &z0, &first, &cnt, (void*)&d_sdf, (void*)&d_nrm, &axes_off};
-        int r = launch(c, fn, sweep_grid(c, tiles, (d_sdf && !d_nrm && c->light_scene) ? 8u : 0u), DCSG_BLOCK, lds, s, args);
+        void* args[] = {(void*)&blob, &nv, &L, &z0, &first, &cnt, (void*)&d_sdf, (void*)&d_nrm, &axes_off, &flags};
+        unsigned grid = sweep_grid(c, tiles, (d_sdf && !d_nrm && c->light_scene) ? 8u : 0u);
+        int r = launch(c, fn, grid, DCSG_BLOCK, lds, s, args);
         if (r) return r;
     }
     if (time_it) {
@@ -410,6 +490,7 @@ int dcsg_create(dcsg_ctx** out, int device_id)
     Lap lap(c->profile_create);
     auto bail = [&](int code) {
         g_create_error = c->err;
+        *out = nullptr;
         dcsg_destroy(c);
         return code;
     };
@@ -461,6 +542,16 @@ int dcsg_create(dcsg_ctx** out, int device_id)
     }
     c->ad_host.assign(DCSG_ARBITRARY_DATA_POINTS, 0.0f);
     lap.mark("lookup_table");
+    // The arbitrary-data table exists from the start (all zeros), uploaded and read back through pageable host memory:
+    // the HIP runtime sets up its staging buffers for pageable copies on the first one of a process (about 7 ms, which
+    // rounds 1-2 paid in the first dcsg_load_scene); a host creates its context once, at start-up.
+    if (ensure(c, c->d_ad, DCSG_ARBITRARY_DATA_POINTS * sizeof(float))) {
+        *out = nullptr;
+        return bail(DCSG_ERR_HIP);
+    }
+    CK(hipMemcpy(c->d_ad.p, c->ad_host.data(), DCSG_ARBITRARY_DATA_POINTS * sizeof(float), hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->ad_host.data(), c->d_ad.p, 4096, hipMemcpyDeviceToHost));
+    lap.mark("arbitrary_data_table_and_copy_path");
     return 0;
 #undef CK
 }
@@ -476,7 +567,9 @@ void dcsg_destroy(dcsg_ctx* c)
                       &c->d_rt_keep, &c->d_rt_out};
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    join_rest_thread(c);
     if (c->scene_mod) hipModuleUnload(c->scene_mod);
+    if (c->scene_mod_rest) hipModuleUnload(c->scene_mod_rest);
     if (c->preview_mod) hipModuleUnload(c->preview_mod);
     if (c->builtin_mod) hipModuleUnload(c->builtin_mod);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -504,7 +597,7 @@ int dcsg_render_preview(dcsg_ctx* c, const float campos[3], const float right[3]
         std::string text = c->scene_cl_text.empty() ? std::string(builtin_scene_cl()) : c->scene_cl_text;
         std::string hsaco, log;
         Scene none;
-        if (!jit_scene_module(text, specialised_source(none, false, false, false), hsaco, log, nullptr))
+        if (!jit_scene_module(text, specialised_source(none, false, false, false), hsaco, log, nullptr, false, false, JIT_PART_REST))
             return fail(c, DCSG_ERR_BUILD, "Error when building preview program:\n" + log);
         HIPCHK(c, hipModuleLoadData(&c->preview_mod, hsaco.data()));
         hipFunction_t set_ad = nullptr;
@@ -557,6 +650,7 @@ int dcsg_set_arbitrary_data(dcsg_ctx* c, const float* data, size_t items)
         void* ad = c->d_ad.p;
         void* args[] = {&ad};
         if ((r = launch(c, c->ks.set_ad, 1, 64, 0, c->stream, args))) return r;
+        if (c->scene_mod_rest && (r = launch(c, c->ks.set_ad_rest, 1, 64, 0, c->stream, args))) return r;
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return 0;
@@ -572,6 +666,7 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     Lap lap(c->profile_load);
     Scene s;
     std::string err;
+    bool sync_rest = false;
     if (!parse_scene(scene_txt, bp_txt, s, err)) return fail(c, DCSG_ERR_INVALID, err);
     lap.mark("parse_and_optimise");
     ModulePlan plan;
@@ -581,10 +676,13 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
         build_blob(s, true);
         c->k = &c->kb;
         c->jit = false;
+        join_rest_thread(c);
+        c->rest_wanted = false;
     } else {
         std::string hsaco, log;
         bool cached = false;
-        if (!jit_scene_module(plan.cl, plan.extra, hsaco, log, &cached, plan.relaxed, plan.specialise))
+        join_rest_thread(c);  // a background build for the previous scene
+        if (!jit_scene_module(plan.cl, plan.extra, hsaco, log, &cached, plan.relaxed, plan.specialise, JIT_PART_EXPORT))
             return fail(c, DCSG_ERR_BUILD, "Error when building evaluation program:\n" + log);
         lap.mark(cached ? "code_object_from_cache" : "code_object_compiled");
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -592,17 +690,44 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
             HIPCHK(c, hipModuleUnload(c->scene_mod));
             c->scene_mod = nullptr;
         }
+        if (c->scene_mod_rest) {
+            HIPCHK(c, hipModuleUnload(c->scene_mod_rest));
+            c->scene_mod_rest = nullptr;
+        }
         HIPCHK(c, hipModuleLoadData(&c->scene_mod, hsaco.data()));
         lap.mark("module_load_scene");
-        int r = load_kernels(c, c->scene_mod, c->ks, plan.specialise ? 1 : 2);
+        int r = load_kernels(c, c->scene_mod, c->ks, plan.specialise ? 1 : 2, 1);
         if (r) return r;
         lap.mark("kernel_lookup");
+        // the rest part: from the cache on first use, or -- after a cold build -- compiled by a background thread while
+        // the caller goes on (the export needs nothing of it); DCSG_JIT_SYNC=1 builds it here instead
+        c->rest_wanted = true;
+        c->rest_kind = plan.specialise ? 1 : 2;
+        c->rest_cl = plan.cl;
+        c->rest_extra = plan.extra;
+        c->rest_relaxed = plan.relaxed;
+        c->rest_spec = plan.specialise;
+        c->rest_hsaco.clear();
+        c->rest_log.clear();
+        c->rest_thread_ok = false;
+        if (!cached) {
+            if (getenv("DCSG_JIT_SYNC")) {
+                sync_rest = true;
+            } else {
+                c->rest_thread = std::thread([c] {
+                    bool from_cache = false;
+                    c->rest_thread_ok = jit_scene_module(c->rest_cl, c->rest_extra, c->rest_hsaco, c->rest_log, &from_cache, c->rest_relaxed,
+                                                         c->rest_spec, JIT_PART_REST);
+                });
+            }
+        }
         build_blob(s, plan.null0);
         c->k = &c->ks;
         c->jit = true;
     }
     c->specialised = c->jit && plan.specialise;
     c->light_scene = plan.light;
+    c->row_kernels = c->jit && plan.specialise && plan.rows;
     c->scene_relaxed = plan.relaxed;
     // every kernel stages the scene tables in LDS: they must fit one workgroup's share (160 KiB on gfx950)
     if (s.lds_bytes() > c->max_lds)
@@ -641,9 +766,36 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     }
     std::fill(c->ad_host.begin(), c->ad_host.end(), 0.0f);
     lap.mark("tables_upload");
-    r = dcsg_set_arbitrary_data(c, ad, ad ? n_ad : 0);
+    // arbitrary_data (DesignCSG.cpp:507-529; all 131 072 floats reach the device, Evaluator.cpp:215-223).  Most designs
+    // leave the table empty: an all-zero table is a device-side memset, not a 512 KB copy through a host staging buffer.
+    if (ad && n_ad > DCSG_ARBITRARY_DATA_POINTS) return fail(c, DCSG_ERR_INVALID, "more than 131072 arbitrary data items");
+    bool all_zero = true;
+    if (ad)
+        for (size_t i = 0; i < n_ad && all_zero; i++) {
+            uint32_t w;
+            memcpy(&w, ad + i, 4);
+            all_zero = w == 0;
+        }
+    if ((r = ensure(c, c->d_ad, DCSG_ARBITRARY_DATA_POINTS * sizeof(float)))) return r;
+    if (all_zero) {
+        HIPCHK(c, hipMemsetAsync(c->d_ad.p, 0, DCSG_ARBITRARY_DATA_POINTS * sizeof(float), c->stream));
+    } else {
+        memcpy(c->ad_host.data(), ad, n_ad * sizeof(float));
+        HIPCHK(c, hipMemcpyAsync(c->d_ad.p, c->ad_host.data(), DCSG_ARBITRARY_DATA_POINTS * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
     lap.mark("arbitrary_data_upload");
-    return r;
+    if (c->jit) {  // the scene module's `arbitrary_data` pointer; also the first launch on the freshly loaded module
+        void* adp = c->d_ad.p;
+        void* args[] = {&adp};
+        if ((r = launch(c, c->ks.set_ad, 1, 64, 0, c->stream, args))) return r;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    lap.mark("first_launch_on_module");
+    if (sync_rest) {
+        if ((r = need_rest(c))) return r;
+        lap.mark("rest_part_compiled_and_loaded");
+    }
+    return 0;
 }
 
 const char* dcsg_load_profile(const dcsg_ctx* c, int which)
@@ -826,7 +978,7 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
     P.has_normals = d_normals ? 1 : 0;
     P.z_own_lo = z_own_lo;
     P.z_own_hi = z_own_hi;
-    P.use_spec = (c->specialised && !getenv("DCSG_MESH_NO_SPEC")) ? 1 : 0;
+    P.use_spec = c->specialised ? 1 : 0;  // informational: a module of the specialised set samples through its per-scene code
 
     // mesh.hpp:110-125: levels 0 and 1 are subdivided unconditionally; the 64 level-2 nodes start the
     // traversal.  Child centre = center + ((hd*sign)*0.5f), child hd = 0.5f*hd (octree.hpp:24-32).
@@ -1106,6 +1258,7 @@ int dcsg_retopologize(dcsg_ctx* c, const float center[3], float diameter, int mi
         return fail(c, DCSG_ERR_INVALID, "retopologize needs 0 <= gridLevel - minimumOctreeLevel <= 5 and gridLevel <= 12");
     if (c->n_tris == 0) return 0;
     if (c->n_tris * 3 > (1ull << 30)) return fail(c, DCSG_ERR_INVALID, "too many vertices for the cell set");
+    if ((r = need_rest(c))) return r;
     hipStream_t s = (hipStream_t)stream;
     DcsgRetopo R;
     for (int k = 0; k < 3; k++) {
@@ -1608,6 +1761,8 @@ int dcsg_debug_sqrt_device(dcsg_ctx* c, const float* d_in, size_t n, float* d_ou
     HIPCHK(c, hipSetDevice(c->device));
     unsigned cnt = (unsigned)n;
     void* args[] = {(void*)&d_in, (void*)&d_out, &cnt};
+    if (c->scene_loaded)
+        if (int rr = need_rest(c)) return rr;
     hipFunction_t f = (c->scene_loaded && c->jit) ? c->ks.test_sqrt : c->kb.test_sqrt;
     return launch(c, f, (unsigned)c->n_cu * 16u, DCSG_BLOCK, 0, (hipStream_t)stream, args);
 }
@@ -1618,6 +1773,8 @@ int dcsg_debug_normal_device(dcsg_ctx* c, const float* d_in, size_t n, float dy,
     HIPCHK(c, hipSetDevice(c->device));
     unsigned cnt = (unsigned)n;
     void* args[] = {(void*)&d_in, (void*)&d_out, &cnt, &dy, &dz, &mixed};
+    if (c->scene_loaded)
+        if (int rr = need_rest(c)) return rr;
     hipFunction_t f = (c->scene_loaded && c->jit) ? c->ks.test_normal : c->kb.test_normal;
     return launch(c, f, (unsigned)c->n_cu * 16u, DCSG_BLOCK, 0, (hipStream_t)stream, args);
 }
@@ -1639,8 +1796,13 @@ int dcsg_jit_prebuild_scene_numerics(const char* scene_txt, const char* bp_txt, 
     if (!parse_scene(scene_txt, bp_txt, s, err) || !plan_scene_module(s, scene_cl, plan, err, numerics == DCSG_NUMERICS_RELAXED)) {
         log = err;
         rc = DCSG_ERR_INVALID;
-    } else if (plan.needs_jit && !jit_scene_module(plan.cl, plan.extra, hsaco, log, &cached, plan.relaxed, plan.specialise)) {
-        rc = DCSG_ERR_BUILD;
+    } else if (plan.needs_jit) {
+        cached = true;
+        for (int part = 0; part < 2 && rc == 0; part++) {
+            bool c1 = false;
+            if (!jit_scene_module(plan.cl, plan.extra, hsaco, log, &c1, plan.relaxed, plan.specialise, part)) rc = DCSG_ERR_BUILD;
+            cached = cached && c1;
+        }
     }
     if (from_cache) *from_cache = cached ? 1 : 0;
     if (log_out && log_cap) {

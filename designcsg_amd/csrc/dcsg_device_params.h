@@ -6,6 +6,11 @@
 #define DCSG_BLOCK 256
 #define DCSG_WAVE 64
 #define DCSG_MAX_SLOTS 64  /* STACK_MEMORY_PER_PIXEL, Evaluator.cpp:7 */
+/* dcsg_sweep* `flags`: bit 0 = the lattice holds no -0.0 coordinate (checked by the host), so the sweep may evaluate
+ * four points per lane with shared unperturbed coordinates (kernels.hip, dcsg_run4) */
+#define DCSG_SWEEP_ROWS 1u
+/* bit 1 = the stack interpreters may serve several 64-point passes with one interpretation of the program */
+#define DCSG_SWEEP_MULTIPASS 2u
 
 struct DcsgLattice {  // ISV3D64 geometry, ISV.hpp:91-109
     float base[3];    // center - 0.5f*diameters   (ISV.hpp:104)

@@ -18,6 +18,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <sstream>
 #include <vector>
@@ -236,8 +237,25 @@ static std::string collect(amd_comgr_data_set_t set, amd_comgr_data_kind_t kind)
     return out;
 }
 
+static bool run_action_(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, const std::vector<const char*>& opts,
+                        amd_comgr_data_set_t in, amd_comgr_data_set_t out, std::string& log);
+
+// DCSG_JIT_PROFILE=1: seconds per comgr action on stderr (where a cold build spends its time)
 static bool run_action(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, const std::vector<const char*>& opts,
                        amd_comgr_data_set_t in, amd_comgr_data_set_t out, std::string& log)
+{
+    static const bool profile = getenv("DCSG_JIT_PROFILE") != nullptr;
+    if (!profile) return run_action_(kind, lang, opts, in, out, log);
+    timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    bool ok = run_action_(kind, lang, opts, in, out, log);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    fprintf(stderr, "dcsg jit: comgr action %d: %.3f s\n", (int)kind, (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec));
+    return ok;
+}
+
+static bool run_action_(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, const std::vector<const char*>& opts,
+                        amd_comgr_data_set_t in, amd_comgr_data_set_t out, std::string& log)
 {
     amd_comgr_action_info_t info;
     if (comgr().amd_comgr_create_action_info(&info) != AMD_COMGR_STATUS_SUCCESS) {
@@ -266,11 +284,12 @@ static bool run_action(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, 
 }
 
 bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, std::string& hsaco, std::string& log,
-                      bool* from_cache, bool relaxed, bool spec_set)
+                      bool* from_cache, bool relaxed, bool spec_set, int part, bool cache_only)
 {
     if (from_cache) *from_cache = false;
     std::string kernels_bc;
-    std::string bc_path = library_dir() + (relaxed ? "/dcsg_kernels_relaxed_" : "/dcsg_kernels_") + (spec_set ? "spec.bc" : "interp.bc");
+    std::string bc_path = library_dir() + (relaxed ? "/dcsg_kernels_relaxed_" : "/dcsg_kernels_") + (spec_set ? "spec" : "interp") +
+                          (part == JIT_PART_REST ? "_rest.bc" : "_export.bc");
     if (!read_file(bc_path, kernels_bc)) {
         log = "cannot read " + bc_path + " (run __graft_entry__.build())";
         return false;
@@ -330,6 +349,7 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
         return true;
     }
     hsaco.clear();
+    if (cache_only) return false;
 
     if (!comgr().handle || !comgr().error.empty()) {
         log = "cannot load the ROCm code object manager (libamd_comgr.so.3):\n" + comgr().error;
@@ -375,10 +395,14 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
 extern "C" int dcsg_jit_prebuild(const char* scene_cl, char* log_out, size_t log_cap, int* from_cache)
 {
     std::string hsaco, log;
-    bool cached = false;
     dcsg::Scene none;
-    bool ok = dcsg::jit_scene_module(scene_cl ? scene_cl : "", dcsg::specialised_source(none, false, false, false), hsaco, log,
-                                     &cached);
+    bool ok = true, cached = true;
+    for (int part = 0; part < 2 && ok; part++) {
+        bool c1 = false;
+        ok = dcsg::jit_scene_module(scene_cl ? scene_cl : "", dcsg::specialised_source(none, false, false, false), hsaco, log, &c1,
+                                    false, false, part);
+        cached = cached && c1;
+    }
     if (from_cache) *from_cache = cached ? 1 : 0;
     if (log_out && log_cap) {
         strncpy(log_out, log.c_str(), log_cap - 1);

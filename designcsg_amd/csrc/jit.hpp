@@ -12,6 +12,13 @@ bool read_file(const std::string& path, std::string& out);
 // relaxed: the opt-in relaxed-numerics module (kernels.hip built with DCSG_RELAXED: hardware sqrt / rsq, FMA
 // contraction, no IEEE division sequences) instead of the bit-exact one.
 // spec_set: link the lean kernel set of a specialised scene (the _sp kernels + mesher) instead of the interpreters'.
+// part: every kernel set exists in two parts, each its own code object (kernels.hip, DCSG_PART_*): JIT_PART_EXPORT =
+// what dcsg_export launches (stage A, node-wise sweep, mesher, projection, de-duplication), JIT_PART_REST = dense
+// sweeps, point evaluation, T-junction repair, test kernels, preview.  A cold build compiles the export part first and
+// the rest while the export already runs (dcsg_api.cpp: load_rest_part).
+// cache_only: never compile; returns false (log empty) when the code object is not in the cache.
+enum { JIT_PART_EXPORT = 0, JIT_PART_REST = 1 };
 bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, std::string& hsaco, std::string& log,
-                      bool* from_cache, bool relaxed = false, bool spec_set = false);
+                      bool* from_cache, bool relaxed = false, bool spec_set = false, int part = JIT_PART_EXPORT,
+                      bool cache_only = false);
 }  // namespace dcsg

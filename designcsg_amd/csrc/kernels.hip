@@ -27,6 +27,14 @@
 
 #include "dcsg_device_params.h"
 
+// Scene modules are built in two parts (csrc/jit.cpp), so that a cold JIT compiles first what an export launches:
+// DCSG_PART_EXPORT = stage A, node-wise sweep, mesher, projection, de-duplication; DCSG_PART_REST = dense sweeps, point
+// evaluation, T-junction repair, test kernels, preview.  Neither defined (the stand-alone module): everything.
+#if !defined(DCSG_PART_EXPORT) && !defined(DCSG_PART_REST)
+#define DCSG_PART_EXPORT 1
+#define DCSG_PART_REST 1
+#endif
+
 // k2.cl:2-4,12-17
 #define K2_MAX_DISTANCE 64.0
 #define K2_NORMAL_EPSILON 0.005
@@ -167,6 +175,19 @@ extern "C" __device__ float dcsg_spec_eval1(float x, float y, float z);
 // leave out terms with a zero coefficient, which is exact for finite coordinates only -- specialise.cpp)
 extern "C" __device__ float dcsg_spec_eval1x(float x, float y, float z);
 extern "C" __device__ int dcsg_spec_small();  // 1: few objects, row-invariant stencil terms may stay in registers
+// Four lattice points per lane (dcsg_run4).  Generated for scenes of standard brushes with at most four object
+// evaluations (dcsg_spec_row4_ok() = 1), stubs otherwise.  dcsg_spec_row4: element
+// 7 j + k = lattice point j (x.s<j>, y, z) at stencil point k; elements 28 / 29 = unsigned minimum / maximum of the bits
+// of the square roots' first estimates (scene_prelude.cl: dcsg_sqrt_acc).  dcsg_spec_row4_d: the four SDF values, then
+// the same two words.
+typedef float dcsg_cl_float4 __attribute__((ext_vector_type(4)));
+typedef float dcsg_cl_float32 __attribute__((ext_vector_type(32)));
+extern "C" __device__ dcsg_cl_float32 dcsg_spec_row4(dcsg_cl_float4 x, float y, float z);
+extern "C" __device__ dcsg_cl_float8 dcsg_spec_row4_d(dcsg_cl_float4 x, float y, float z);
+// the same with every point's own y and z (a run that crosses a row end)
+extern "C" __device__ dcsg_cl_float32 dcsg_spec_row4g(dcsg_cl_float4 x, dcsg_cl_float4 y, dcsg_cl_float4 z);
+extern "C" __device__ dcsg_cl_float8 dcsg_spec_row4g_d(dcsg_cl_float4 x, dcsg_cl_float4 y, dcsg_cl_float4 z);
+extern "C" __device__ int dcsg_spec_row4_ok();
 #define DCSG_HAVE_SPEC 1
 #endif
 #else
@@ -224,12 +245,12 @@ struct SceneLds {
     int n_stack_steps;
     int n_regs;
     int flags;
+    int n_vec4;  // size of the blob: dcsg_scene_view(n_vec4) finds the tables again
 };
 
-__device__ __forceinline__ SceneLds dcsg_stage_scene(const uint4* __restrict__ blob, int n_vec4)
+// the tables as they lie in LDS once dcsg_stage_scene has copied them
+__device__ __forceinline__ SceneLds dcsg_scene_view(int n_vec4)
 {
-    for (int i = threadIdx.x; i < n_vec4; i += DCSG_BLOCK) dcsg_lds[i] = blob[i];
-    __syncthreads();
     SceneLds s;
     int n_steps = __builtin_amdgcn_readfirstlane((int)dcsg_lds[0].x);
     s.n_steps = n_steps;
@@ -244,7 +265,14 @@ __device__ __forceinline__ SceneLds dcsg_stage_scene(const uint4* __restrict__ b
     s.items = reinterpret_cast<const int4*>(dcsg_lds + 2 + n_steps + n_stack);
     s.obj = reinterpret_cast<const float4*>(dcsg_lds + 2 + n_steps + n_stack + n_items);
     s.stack = reinterpret_cast<float*>(dcsg_lds + n_vec4) + threadIdx.x;
+    s.n_vec4 = n_vec4;
     return s;
+}
+__device__ __forceinline__ SceneLds dcsg_stage_scene(const uint4* __restrict__ blob, int n_vec4)
+{
+    for (int i = threadIdx.x; i < n_vec4; i += DCSG_BLOCK) dcsg_lds[i] = blob[i];
+    __syncthreads();
+    return dcsg_scene_view(n_vec4);
 }
 
 // Internal opcodes: the host (csrc/scene.cpp, fuse_program) rewrites the reference's
@@ -386,23 +414,33 @@ __device__ __forceinline__ void dcsg_finish_normal(float Dx, float Dy, float Dz,
 // OpenCL normalize(float3) pinned as v / length(v), zero vector stays zero.
 // dcsg_normalize_fast: the quotients through one shared reciprocal when every lane of the wave has ordinary operands
 // (returns true); otherwise nothing is written and the caller takes dcsg_normalize_plain.
+// Ordinary: every component is a zero or at least 2^-60 in magnitude, and the length is at most 2^60.  An exactly zero
+// component is common -- lattice points on a symmetry plane of the scene, where the two stencil values of an axis are
+// equal (one 64-point pass in eight at 513 points per row with the box centred on a sphere) -- and harmless: 0 * r1 = 0,
+// the residual is 0, the quotient is 0 (the sign of a -0 numerator is put back by the copysign; for every other
+// numerator it is a no-op, the divisor being positive).
+__device__ __forceinline__ unsigned int dcsg_component_key(float c)
+{
+    return (__float_as_uint(c) & 0x7fffffffu) - 1u;  // |c| as an integer, zeros wrapped to the top: key >= bits(2^-60) - 1 <=> ordinary
+}
 __device__ __forceinline__ bool dcsg_normalize_fast(float& x, float& y, float& z, float& len)
 {
     len = dcsg_sqrt(x * x + y * y + z * z);
-    const float lo = 0x1p-60f, hi = 0x1p60f;
-    // components are at most len (1 + 2^-22) in magnitude; a zero, tiny, huge or NaN operand anywhere in the wave
-    // sends the wave through the plain divisions (zero components: lattice points on a symmetry plane)
-    // (len >= every |component| -- the root is correctly rounded and monotone --, so len >= lo follows from the smallest
-    // component; a NaN component makes len NaN, which fails len <= hi)
-    const float smallest = __builtin_fminf(__builtin_fminf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z));
-    const bool plain = !(smallest >= lo && len <= hi);
+    const float hi = 0x1p60f;
+    // components are at most len (1 + 2^-22) in magnitude; a tiny, huge or NaN operand anywhere in the wave sends the
+    // wave through the plain divisions (a NaN component makes len NaN, which fails len <= hi; the zero vector has
+    // len 0 and is left to the plain path, which returns it unchanged)
+    unsigned int k0 = dcsg_component_key(x), k1 = dcsg_component_key(y), k2 = dcsg_component_key(z);
+    unsigned int smallest = k0 < k1 ? k0 : k1;
+    smallest = k2 < smallest ? k2 : smallest;
+    const bool plain = !(smallest >= 0x21800000u - 1u && len <= hi && len > 0.0f);
     if (__builtin_amdgcn_ballot_w64(plain) != 0ull) return false;
     float r = __builtin_amdgcn_rcpf(len);
     float e = __builtin_fmaf(-len, r, 1.0f);
     float r1 = __builtin_fmaf(e, r, r);
-    x = dcsg_div_by(x, len, r1);
-    y = dcsg_div_by(y, len, r1);
-    z = dcsg_div_by(z, len, r1);
+    x = __builtin_copysignf(dcsg_div_by(x, len, r1), x);
+    y = __builtin_copysignf(dcsg_div_by(y, len, r1), y);
+    z = __builtin_copysignf(dcsg_div_by(z, len, r1), z);
     return true;
 }
 __device__ __forceinline__ void dcsg_normalize_plain(float& x, float& y, float& z, float len)
@@ -446,6 +484,58 @@ __device__ __forceinline__ void dcsg_finish_normal(float Dx, float Dy, float Dz,
 }
 #endif
 
+// dcsg_finish_normal's fast path WITHOUT its own branch, for code that finishes several normals side by side (the row
+// kernels): the operand tests are folded into running unsigned minima / maxima -- gmn / gmx: bits of the square root's
+// first estimate (dcsg_sqrt); smn: bits of the smallest |component|; lmx: bits of the length -- and the caller tests them
+// once (dcsg_normal_acc_bad); where the test fails it recomputes through dcsg_finish_normal.  Same bits wherever it passes.
+struct DcsgNormalAcc {
+    unsigned int gmn, gmx, smn, lmx;
+};
+__device__ __forceinline__ DcsgNormalAcc dcsg_normal_acc_init(unsigned int gmn, unsigned int gmx)
+{
+    return {gmn, gmx, 0x3f800000u, 0x3f800000u};
+}
+__device__ __forceinline__ bool dcsg_normal_acc_bad(const DcsgNormalAcc& a)
+{
+    // square roots: 2^-48 <= g < inf; normalize (dcsg_normalize_fast): every component a zero or >= 2^-60 in magnitude
+    // (dcsg_component_key), length <= 2^60 (a NaN component makes the length NaN, and the zero vector's squared length 0
+    // gives rsq(0) * 0 = NaN: both fail the gmx test)
+    return a.gmn < 0x27800000u || a.gmx >= 0x7f800000u || a.smn < 0x21800000u - 1u || a.lmx > 0x5d800000u;
+}
+__device__ __forceinline__ void dcsg_finish_normal_acc(float Dx, float Dy, float Dz, float& nx, float& ny, float& nz, DcsgNormalAcc& a)
+{
+#ifdef DCSG_RELAXED
+    dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
+#else
+    const float twoE = (float)(2.0 * K2_NORMAL_EPSILON);
+    const double k = 1.0 / (double)twoE;
+    const float kh = (float)k, kl = (float)(k - (double)kh);
+    nx = __builtin_fmaf(kh, Dx, kl * Dx);
+    ny = __builtin_fmaf(kh, Dy, kl * Dy);
+    nz = __builtin_fmaf(kh, Dz, kl * Dz);
+    const float q = nx * nx + ny * ny + nz * nz;
+    float y = __builtin_amdgcn_rsqf(q);
+    float g = q * y;
+    float h = 0.5f * y;
+    float d = __builtin_fmaf(-g, g, q);
+    const float len = __builtin_fmaf(d, h, g);
+    const unsigned int gb = __float_as_uint(g), lb = __float_as_uint(len);
+    const unsigned int s0 = dcsg_component_key(nx), s1 = dcsg_component_key(ny), s2 = dcsg_component_key(nz);
+    a.gmn = gb < a.gmn ? gb : a.gmn;
+    a.gmx = gb > a.gmx ? gb : a.gmx;
+    unsigned int sm = s0 < s1 ? s0 : s1;
+    sm = s2 < sm ? s2 : sm;
+    a.smn = sm < a.smn ? sm : a.smn;
+    a.lmx = lb > a.lmx ? lb : a.lmx;
+    float r = __builtin_amdgcn_rcpf(len);
+    float e = __builtin_fmaf(-len, r, 1.0f);
+    float r1 = __builtin_fmaf(e, r, r);
+    nx = __builtin_copysignf(dcsg_div_by(nx, len, r1), nx);
+    ny = __builtin_copysignf(dcsg_div_by(ny, len, r1), ny);
+    nz = __builtin_copysignf(dcsg_div_by(nz, len, r1), nz);
+#endif
+}
+
 // get_normal, k2.cl:149-179
 __device__ __forceinline__ void dcsg_get_normal(const SceneLds& s, float x, float y, float z, float& nx, float& ny,
                                                 float& nz)
@@ -459,8 +549,12 @@ __device__ __forceinline__ void dcsg_get_normal(const SceneLds& s, float x, floa
 }
 
 // Out-of-line copies for the rare exact path of the fast kernels (keeps their code small).
-__device__ __noinline__ float dcsg_primary_sdf_slow(const SceneLds& s, float x, float y, float z)
+// The scene tables are found again from their place in LDS (dcsg_scene_view) instead of through a reference to the
+// caller's SceneLds: a struct whose address is passed to a real call has to live in scratch memory, 80 bytes per lane
+// that rounds 1-2 carried in every kernel with this path.
+__device__ __noinline__ float dcsg_primary_sdf_slow(int n_vec4, float x, float y, float z)
 {
+    SceneLds s = dcsg_scene_view(n_vec4);
     return dcsg_primary_sdf(s, x, y, z);
 }
 
@@ -673,11 +767,11 @@ __device__ __forceinline__ void dcsg_stencil(const SceneLds& s, float x, float y
     }
     bool nzero = dcsg_is_neg_zero(x) || dcsg_is_neg_zero(y) || dcsg_is_neg_zero(z);
     if (__builtin_amdgcn_ballot_w64(nzero) != 0ull) {
-        if (want_sdf) sdf = dcsg_primary_sdf_slow(s, x, y, z);
+        if (want_sdf) sdf = dcsg_primary_sdf_slow(s.n_vec4, x, y, z);
         const float e = (float)K2_NORMAL_EPSILON, zero = 0.0f;
-        float Dx = dcsg_primary_sdf_slow(s, x + e, y + zero, z + zero) - dcsg_primary_sdf_slow(s, x - e, y - zero, z - zero);
-        float Dy = dcsg_primary_sdf_slow(s, x + zero, y + e, z + zero) - dcsg_primary_sdf_slow(s, x - zero, y - e, z - zero);
-        float Dz = dcsg_primary_sdf_slow(s, x + zero, y + zero, z + e) - dcsg_primary_sdf_slow(s, x - zero, y - zero, z - e);
+        float Dx = dcsg_primary_sdf_slow(s.n_vec4, x + e, y + zero, z + zero) - dcsg_primary_sdf_slow(s.n_vec4, x - e, y - zero, z - zero);
+        float Dy = dcsg_primary_sdf_slow(s.n_vec4, x + zero, y + e, z + zero) - dcsg_primary_sdf_slow(s.n_vec4, x - zero, y - e, z - zero);
+        float Dz = dcsg_primary_sdf_slow(s.n_vec4, x + zero, y + zero, z + e) - dcsg_primary_sdf_slow(s.n_vec4, x - zero, y - zero, z - e);
         dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
         return;
     }
@@ -1052,6 +1146,79 @@ __device__ __forceinline__ void dcsg_wave_advance(unsigned int n1, unsigned int&
     }
 }
 
+// write-once streaming output: non-temporal stores (nothing in the sweeps reads the lattice back)
+#ifdef DCSG_NO_NT_STORES
+#define DCSG_STREAM_STORE(v, p) (*(p) = (v))
+#else
+#define DCSG_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
+#ifdef DCSG_HAVE_SPEC
+// ---------------------------------------------------------------------------
+// Four lattice points per lane for store-bound scenes (standard brushes, at most four object evaluations:
+// dcsg_spec_row4_ok()): in a run of 256 consecutive points a LANE OWNS the points lane, lane + 64, lane + 128, lane + 192,
+// i.e. its share of each of the run's four 64-point passes, so that the stores keep the flat kernel's shape (per
+// instruction a wave writes 256 contiguous, 256-byte-aligned bytes of SDF or 768 of normals) while
+//   * the 28 (SDF only: 4) square roots and the 4 normalisations run side by side in one basic block, their operand tests
+//     folded into four running minima / maxima that are tested ONCE per run (dcsg_normal_acc_bad) -- the per-root
+//     compare-and-branch of dcsg_sqrt is gone and the chains are free to overlap; a wave that fails the test (tiny, zero,
+//     huge or NaN operands: lattice points on a symmetry plane of the scene, where a gradient component is exactly zero)
+//     recomputes its four points through the guarded code, so the results are bit-identical to it everywhere;
+//   * in a run that lies inside one lattice row, y and z and everything the seven stencil evaluations derive from them
+//     alone are shared by the lane's four points (value numbering over dcsg_spec_row4's straight-line code: same
+//     operations, same bits); a run that crosses a row end takes dcsg_spec_row4g, every point with its own y and z.
+// What did NOT work, measured (profiles/r03_ab_rows.txt, tools/write_patterns2.hip): runs aligned to the lattice ROWS
+// (segments of 256 points starting at a row start) -- rows hold 2^k + 1 points, so every store then starts at an odd
+// 4-byte offset, every instruction leaves two partial 128-byte lines to another wave, and the sweep takes 1.5-2x as
+// long; a lane owning four CONSECUTIVE points with 16-byte stores at a 48-byte stride for the normals: 0.70 of the
+// HBM peak as plain stores and 0.27 as non-temporal ones, against 0.80 for the pattern kept here.
+// The host sets DCSG_SWEEP_ROWS only for lattices without a -0.0 coordinate (the stencil's "+ 0.0f" would change it:
+// dcsg_stencil_spec).
+// ---------------------------------------------------------------------------
+// x, y, z: the lane's four points (pass j of the run); in_row: y and z are the same for all four (wave-uniform)
+template <int MODE>
+__device__ __forceinline__ void dcsg_run4(const dcsg_cl_float4& x, const dcsg_cl_float4& y, const dcsg_cl_float4& z, bool in_row,
+                                          float* __restrict__ sdf_at, float* __restrict__ nrm_at)
+{
+    if (MODE == 1) {
+        dcsg_cl_float8 v = in_row ? dcsg_spec_row4_d(x, y[0], z[0]) : dcsg_spec_row4g_d(x, y, z);
+        const unsigned int gmn = __float_as_uint(v[4]), gmx = __float_as_uint(v[5]);
+        float sd[4] = {v[0], v[1], v[2], v[3]};
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(gmn < 0x27800000u || gmx >= 0x7f800000u) != 0ull, 0)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) sd[j] = dcsg_spec_eval1(x[j], y[j], z[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) DCSG_STREAM_STORE(sd[j], sdf_at + 64 * j);
+    } else {
+        dcsg_cl_float32 v = in_row ? dcsg_spec_row4(x, y[0], z[0]) : dcsg_spec_row4g(x, y, z);
+        DcsgNormalAcc acc = dcsg_normal_acc_init(__float_as_uint(v[28]), __float_as_uint(v[29]));
+        float sd[4], nx[4], ny[4], nz[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            sd[j] = v[7 * j];
+            dcsg_finish_normal_acc(v[7 * j + 1] - v[7 * j + 2], v[7 * j + 3] - v[7 * j + 4], v[7 * j + 5] - v[7 * j + 6], nx[j], ny[j], nz[j],
+                                   acc);
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(dcsg_normal_acc_bad(acc)) != 0ull, 0)) {
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                float a = 0.0f, b = 0.0f, c = 0.0f, d = 0.0f;
+                dcsg_stencil_spec<true>(x[j], y[j], z[j], true, true, a, b, c, d);
+                sd[j] = a, nx[j] = b, ny[j] = c, nz[j] = d;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            DCSG_STREAM_STORE(sd[j], sdf_at + 64 * j);
+            DCSG_STREAM_STORE(nx[j], nrm_at + 192 * j);
+            DCSG_STREAM_STORE(ny[j], nrm_at + 192 * j + 1);
+            DCSG_STREAM_STORE(nz[j], nrm_at + 192 * j + 2);
+        }
+    }
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // Kernel 1: fused lattice sweep.  One thread per lattice point, x fastest, so a wave stores
 // 256 contiguous bytes of SDF and 768 contiguous bytes of normals per pass; a wave owns a run of
@@ -1065,10 +1232,12 @@ __device__ __forceinline__ void dcsg_wave_advance(unsigned int n1, unsigned int&
 // paths in the loop); MODE 0 reads them off the pointers at run time (normals only, and the kernels kept small).
 // ---------------------------------------------------------------------------
 #define DCSG_RUN (4u * DCSG_WAVE)
+
 template <int K, int MODE>
 __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, int n_vec4, const DcsgLattice& L, int z0,
                                                 unsigned int first, unsigned int n_points,
-                                                float* __restrict__ sdf_out, float* __restrict__ nrm_out, int axes_off)
+                                                float* __restrict__ sdf_out, float* __restrict__ nrm_out, int axes_off,
+                                                unsigned int flags)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     const float* ax = dcsg_stage_axes(L, axes_off);
@@ -1092,7 +1261,80 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             iy0 = t0 - iz0 * n1;
             plane0 = iz0 + (unsigned int)z0;                                // ... to here
         }
+        // Stack interpreters: ONE interpretation of the program serves several of the run's four 64-point passes -- the
+        // step decode (LDS record, readfirstlane, opcode / brush / depth branches: scalar work, ~35 instructions per step)
+        // is paid per 256 points (SDF only: the lane's point of each of the four passes) or per 128 (SDF + normals: two
+        // passes x seven stencil points) instead of per 64.  Same arithmetic per point: same bits.
+        if (K > 0 && MODE == 1 && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_MULTIPASS)) {
+            float px[4], py[4], pz[4], o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
+                px[j] = w.x, py[j] = w.y, pz[j] = w.z;
+                dcsg_wave_advance(n1, ix0, iy0, plane0);
+            }
+            dcsg_interp<(K <= 0 ? 4 : K), 4>(s, px, py, pz, o);
+#pragma unroll
+            for (int j = 0; j < 4; j++) DCSG_STREAM_STORE(o[j], sdf_out + idx0 + lane + 64 * j);
+            continue;
+        }
+        if (K > 0 && MODE == 3 && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_ROWS) && (flags & DCSG_SWEEP_MULTIPASS)) {  // no -0.0 coordinate
+            const float e = (float)K2_NORMAL_EPSILON;
+#pragma unroll 1
+            for (int half = 0; half < 2; half++) {
+                float px[14], py[14], pz[14], o[14];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
+                    dcsg_wave_advance(n1, ix0, iy0, plane0);
+                    const float xp = w.x + e, xm = w.x - e, yp = w.y + e, ym = w.y - e, zp = w.z + e, zm = w.z - e;
+                    const float qx[7] = {w.x, xp, xm, w.x, w.x, w.x, w.x}, qy[7] = {w.y, w.y, w.y, yp, ym, w.y, w.y},
+                                qz[7] = {w.z, w.z, w.z, w.z, w.z, zp, zm};
+#pragma unroll
+                    for (int k = 0; k < 7; k++) px[7 * j + k] = qx[k], py[7 * j + k] = qy[k], pz[7 * j + k] = qz[k];
+                }
+                dcsg_interp<(K <= 0 ? 4 : K), 14>(s, px, py, pz, o);
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    float nx, ny, nz;
+                    dcsg_finish_normal(o[7 * j + 1] - o[7 * j + 2], o[7 * j + 3] - o[7 * j + 4], o[7 * j + 5] - o[7 * j + 6], nx, ny, nz);
+                    const unsigned int at = idx0 + lane + 64u * (unsigned int)(2 * half + j);
+                    DCSG_STREAM_STORE(o[7 * j], sdf_out + at);
+                    float* q = nrm_out + (size_t)at * 3;
+                    DCSG_STREAM_STORE(nx, q);
+                    DCSG_STREAM_STORE(ny, q + 1);
+                    DCSG_STREAM_STORE(nz, q + 2);
+                }
+            }
+            continue;
+        }
 #ifdef DCSG_HAVE_SPEC
+        if (K < 0 && (MODE == 1 || MODE == 3) && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_ROWS) && dcsg_spec_row4_ok()) {
+            // four points per lane (dcsg_run4): the lane's share of each of the run's four passes
+            dcsg_cl_float4 x4, y4, z4;
+#ifdef DCSG_EXPERIMENT_ALL_IN_ROW  // timing experiment only (wrong values at row ends): every run through the shared-y/z code
+            const bool in_row = true;
+#else
+            const bool in_row = ix0 + DCSG_RUN <= n1;  // wave-uniform
+#endif
+            if (in_row) {
+                const float* xr = ax + ix0 + lane;
+#pragma unroll
+                for (int j = 0; j < 4; j++) x4[j] = xr[64 * j];
+                const float y = ax[n1 + iy0], z = ax[2u * n1 + plane0];
+                y4 = y;
+                z4 = z;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
+                    x4[j] = w.x, y4[j] = w.y, z4[j] = w.z;
+                    dcsg_wave_advance(n1, ix0, iy0, plane0);
+                }
+            }
+            dcsg_run4<MODE>(x4, y4, z4, in_row, sdf_out + idx0 + lane, MODE == 3 ? nrm_out + (size_t)idx0 * 3 + lane * 3u : nullptr);
+            continue;
+        }
         // Small scenes: passes that lie inside one lattice row share y and z, so everything the seven stencil evaluations
         // derive from those two alone is computed once for the passes of a row segment (loop-invariant code motion: same
         // operations, same bits), and the per-pass row tests disappear.
@@ -1203,15 +1445,17 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
 #define DCSG_SWEEP_KERNEL(NAME, K, MODE)                                                                            \
     extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                        \
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,                     \
-         unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out, int axes_off)             \
+         unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out, int axes_off,             \
+         unsigned int flags)                                                                                        \
     {                                                                                                               \
-        dcsg_sweep_body<K, MODE>(blob, n_vec4, L, z0, first, n_points, sdf_out, nrm_out, axes_off);                 \
+        dcsg_sweep_body<K, MODE>(blob, n_vec4, L, z0, first, n_points, sdf_out, nrm_out, axes_off, flags);          \
     }
 // NAME: outputs chosen at run time; NAME_d: SDF only; NAME_f: SDF + normals
 #define DCSG_SWEEP_KERNELS(NAME, K)                                                                                 \
     DCSG_SWEEP_KERNEL(NAME, K, 0)                                                                                   \
     DCSG_SWEEP_KERNEL(NAME##_d, K, 1)                                                                               \
     DCSG_SWEEP_KERNEL(NAME##_f, K, 3)
+#ifdef DCSG_PART_REST
 #ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_SWEEP_KERNELS(dcsg_sweep, 0)
 DCSG_SWEEP_KERNELS(dcsg_sweep_s4, 4)
@@ -1220,6 +1464,8 @@ DCSG_SWEEP_KERNELS(dcsg_sweep_s8, 8)
 #ifdef DCSG_HAVE_SPEC
 DCSG_SWEEP_KERNELS(dcsg_sweep_sp, -1)
 #endif
+#endif  // DCSG_PART_REST
+
 
 // ---------------------------------------------------------------------------
 // Node-wise sweep (dcsg_export): the lattice values of the octree nodes of one level -- the nodes that reached the
@@ -1363,6 +1609,7 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
         dcsg_sweep_nodes_body<K>(blob, n_vec4, L, nodes, n_nodes, shift, level, sdf_out, nrm_out, node_mask, hdx,    \
                                  hdy, hdz, z_own_lo, z_own_hi, n_swept);                                             \
     }
+#ifdef DCSG_PART_EXPORT
 #ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes, 0)
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_s4, 4)
@@ -1372,6 +1619,8 @@ DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_s8, 8)
 DCSG_SWEEP_NODES_KERNEL(dcsg_sweep_nodes_sp, -1)
 
 #endif
+#endif  // DCSG_PART_EXPORT
+
 
 // ---------------------------------------------------------------------------
 // Kernel 2: k2-equivalent point evaluation (Evaluator::eval_sdf_at_points /
@@ -1416,6 +1665,7 @@ __device__ __forceinline__ void dcsg_eval_points_body(const uint4* __restrict__ 
     {                                                                                                               \
         dcsg_eval_points_body<K>(blob, n_vec4, xyz, n, mode, out);                                                  \
     }
+#ifdef DCSG_PART_REST
 #ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_EVAL_KERNEL(dcsg_eval_points, 0)
 DCSG_EVAL_KERNEL(dcsg_eval_points_s4, 4)
@@ -1424,6 +1674,8 @@ DCSG_EVAL_KERNEL(dcsg_eval_points_s8, 8)
 #ifdef DCSG_HAVE_SPEC
 DCSG_EVAL_KERNEL(dcsg_eval_points_sp, -1)
 #endif
+#endif  // DCSG_PART_REST
+
 
 // ---------------------------------------------------------------------------
 // Kernel 3: stage A bounding-box probe, DesignCSG.cpp:668-712.
@@ -1513,6 +1765,7 @@ __device__ __forceinline__ void dcsg_bbox_body(const uint4* __restrict__ blob, i
     {                                                                                                               \
         dcsg_bbox_body<K>(blob, n_vec4, cd, half_neg, bb_eps, result);                                              \
     }
+#ifdef DCSG_PART_EXPORT
 #ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_BBOX_KERNEL(dcsg_bbox, 0)
 DCSG_BBOX_KERNEL(dcsg_bbox_s4, 4)
@@ -1521,6 +1774,8 @@ DCSG_BBOX_KERNEL(dcsg_bbox_s8, 8)
 #ifdef DCSG_HAVE_SPEC
 DCSG_BBOX_KERNEL(dcsg_bbox_sp, -1)
 #endif
+#endif  // DCSG_PART_EXPORT
+
 
 // ---------------------------------------------------------------------------
 // Mesher (Mesh::getSurface, mesh.hpp:148-311) on the dense lattice.
@@ -1588,15 +1843,16 @@ __device__ __forceinline__ float sample_sdf(const Sampler& S, const float p[3])
         return S.sdf[((size_t)(iz - S.P->z_lo) * n1 + iy) * n1 + ix];
     }
 #ifdef DCSG_HAVE_SPEC
-    if (S.P->use_spec) {  // the module's per-scene code (same bits as the interpreter, a fraction of its instructions)
-        float sd, u0, u1, u2;
-        dcsg_stencil_spec<true>(dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy), dcsg_lattice_coord(L, 2, iz), true, false,
-                                sd, u0, u1, u2);
-        return sd;
-    }
-#endif
+    // the module's per-scene code (same bits as the interpreter, a fraction of its instructions); a module of the
+    // specialised kernel set holds no interpreter copy here: every copy is compiled when a scene is first loaded
+    float sd, u0, u1, u2;
+    dcsg_stencil_spec<true>(dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy), dcsg_lattice_coord(L, 2, iz), true, false,
+                            sd, u0, u1, u2);
+    return sd;
+#else
     return dcsg_primary_sdf(*S.scene, dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy),
                             dcsg_lattice_coord(L, 2, iz));
+#endif
 }
 
 __device__ __forceinline__ void sample_normal(const Sampler& S, const float p[3], float n[3])
@@ -1612,15 +1868,13 @@ __device__ __forceinline__ void sample_normal(const Sampler& S, const float p[3]
         return;
     }
 #ifdef DCSG_HAVE_SPEC
-    if (S.P->use_spec) {
-        float sd;
-        dcsg_stencil_spec<true>(dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy), dcsg_lattice_coord(L, 2, iz), false, true,
-                                sd, n[0], n[1], n[2]);
-        return;
-    }
-#endif
+    float sd;
+    dcsg_stencil_spec<true>(dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy), dcsg_lattice_coord(L, 2, iz), false, true,
+                            sd, n[0], n[1], n[2]);
+#else
     dcsg_get_normal(*S.scene, dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy),
                     dcsg_lattice_coord(L, 2, iz), n[0], n[1], n[2]);
+#endif
 }
 
 // Node codes in info[i] (low byte; lookup case in the high byte)
@@ -1629,6 +1883,7 @@ __device__ __forceinline__ void sample_normal(const Sampler& S, const float p[3]
 #define NODE_LEAF 2u       // emits trsMap[lookup] triangles
 #define NODE_LEAF_REMOTE 3u  // leaf whose triangles another rank emits
 
+#ifdef DCSG_PART_EXPORT
 // Node classification.  block_sums[2*b+0] = children of block b, [2*b+1] = triangles of
 // block b.  level_stats: {culled, subdivided, leaves, triangles}, integer atomics, counting
 // only nodes this rank owns so that per-rank stats add up to the single-GPU ones.
@@ -1639,6 +1894,7 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
                    unsigned int* __restrict__ block_sums, unsigned long long* __restrict__ level_stats)
 {
     SceneLds scene = dcsg_stage_scene(blob, n_vec4);
+    __shared__ float corner_normals[8 * 4 * DCSG_BLOCK];  // [corner][x, y, z, length][thread]
     Sampler S = {&P, sdf, nrm, &scene};
     unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x;
     unsigned int code = NODE_SKIP, lookup = 0, n_tri = 0;
@@ -1659,7 +1915,9 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
                 // mesh.hpp:176-183; the corner case is only ever used by a leaf, and a node above the minimum level
                 // is always subdivided (mesh.hpp:214-217), so its corners are not sampled
                 if (P.level >= P.min_level) {
-#pragma unroll
+                    // rolled: one copy of the (per-scene, possibly large) evaluation code instead of eight -- the scene
+                    // module is compiled when a scene is first loaded, and this kernel was the largest part of that
+#pragma unroll 1
                     for (int k = 0; k < 8; k++) {
                         float p[3];
                         dcsg_corner(k, 1.0f, c, P.hd, p);
@@ -1690,20 +1948,26 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
                     // the normal at both ends of each of the 12 edges; those are the 8 corners, three times each, so
                     // they are sampled once (an on-demand normal is six evaluations of the scene).
                     if (!subdivide) {
-                        float cn[8][3], cm[8];
-#pragma unroll
+                        // the corner loop is rolled (one copy of the evaluation code, see above); the eight normals and
+                        // their lengths wait in LDS, slot-major so that every access is conflict-free
+#pragma unroll 1
                         for (int k = 0; k < 8; k++) {
-                            float p[3];
+                            float p[3], n[3];
                             dcsg_corner(k, 1.0f, c, P.hd, p);
-                            sample_normal(S, p, cn[k]);
-                            cm[k] = dcsg_sqrt(cn[k][0] * cn[k][0] + cn[k][1] * cn[k][1] + cn[k][2] * cn[k][2]);
+                            sample_normal(S, p, n);
+                            float* o = corner_normals + (size_t)k * 4 * DCSG_BLOCK + threadIdx.x;
+                            o[0] = n[0];
+                            o[DCSG_BLOCK] = n[1];
+                            o[2 * DCSG_BLOCK] = n[2];
+                            o[3 * DCSG_BLOCK] = dcsg_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
                         }
-#pragma unroll
+#pragma unroll 1
                         for (int e = 0; e < 12; e++) {
-                            const int ia = dcsg_edge_a(e), ib = dcsg_edge_b(e);
-                            float mm = cm[ia] * cm[ib];
+                            const float* a = corner_normals + (size_t)dcsg_edge_a(e) * 4 * DCSG_BLOCK + threadIdx.x;
+                            const float* b = corner_normals + (size_t)dcsg_edge_b(e) * 4 * DCSG_BLOCK + threadIdx.x;
+                            float mm = a[3 * DCSG_BLOCK] * b[3 * DCSG_BLOCK];
                             if (!(mm < 1e-6f)) {
-                                float q = (cn[ia][0] * cn[ib][0] + cn[ia][1] * cn[ib][1] + cn[ia][2] * cn[ib][2]) / mm;
+                                float q = (a[0] * b[0] + a[DCSG_BLOCK] * b[DCSG_BLOCK] + a[2 * DCSG_BLOCK] * b[2 * DCSG_BLOCK]) / mm;
                                 // (float)acos((double)q) > threshold, folded by the host into q_star
                                 if (q >= -1.0f && q <= P.q_star) subdivide = true;
                             }
@@ -1868,6 +2132,8 @@ dcsg_mesh_emit(DcsgMeshParams P, const float* __restrict__ nodes, unsigned int n
     }
 }
 
+#endif  // DCSG_PART_EXPORT (mesher kernels)
+
 // ---------------------------------------------------------------------------
 // Kernel: vertex projection, performGradientDescent mesh.hpp:531-593.
 // p <- p + n(p) * (-sdf(p)), `steps` times, at the true (unsnapped) positions.  All steps of
@@ -1942,6 +2208,7 @@ __device__ __forceinline__ void dcsg_project_body(const uint4* __restrict__ blob
     {                                                                                                               \
         dcsg_project_body<K>(blob, n_vec4, verts, n_verts, steps);                                                  \
     }
+#ifdef DCSG_PART_EXPORT
 #ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
 DCSG_PROJECT_KERNEL(dcsg_project, 0)
 DCSG_PROJECT_KERNEL(dcsg_project_s4, 4)
@@ -1950,6 +2217,8 @@ DCSG_PROJECT_KERNEL(dcsg_project_s8, 8)
 #ifdef DCSG_HAVE_SPEC
 DCSG_PROJECT_KERNEL(dcsg_project_sp, -1)
 #endif
+#endif  // DCSG_PART_EXPORT
+
 
 #ifdef DCSG_HAVE_CULL
 // ---------------------------------------------------------------------------
@@ -2030,7 +2299,8 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
 // is hundreds of object evaluations per point, where store shape is irrelevant next to the work removed.
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_sweep_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,
-              unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out, int /*axes_off: unused*/)
+              unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out, int /*axes_off: unused*/,
+              unsigned int /*flags: unused*/)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     const unsigned int n1 = (unsigned int)L.res + 1u;
@@ -2209,6 +2479,7 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
 }
 #endif
 
+#ifdef DCSG_PART_EXPORT
 // ---------------------------------------------------------------------------
 // Vertex de-duplication for the projection.  The mesher emits an un-indexed triangle soup like the reference
 // (mesh.hpp:283-307), so every surface vertex appears about six times; performGradientDescent moves each copy
@@ -2313,6 +2584,9 @@ dcsg_dedup_scatter(float* __restrict__ verts, const unsigned int* __restrict__ r
     }
 }
 
+#endif  // DCSG_PART_EXPORT (de-duplication)
+
+#ifdef DCSG_PART_REST
 // ---------------------------------------------------------------------------
 // Opt-in: T-junction repair in the spirit of cms::retopologize (mesh.hpp:432-529).  The reference's function is
 // undefined behaviour and unfinished; oracle/dcsg_oracle.c (oracle_retopologize) defines the semantics these kernels
@@ -2538,19 +2812,29 @@ dcsg_test_sqrt(const float* __restrict__ in, float* __restrict__ out, unsigned i
 }
 
 // Diagnostic: dcsg_finish_normal(in[i], dy, dz) over an array (exhaustive test of the float-only gradient scale).
-// mixed: odd lanes take the gradient (1, 2, 3) instead, so a wave holds ordinary and extreme operands side by side.
+// mixed bit 0: odd lanes take the gradient (1, 2, 3) instead, so a wave holds ordinary and extreme operands side by
+// side; bit 1: through dcsg_finish_normal_acc (deferred guard) and its fallback.
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_test_normal(const float* __restrict__ in, float* __restrict__ out, unsigned int n, float dy, float dz, int mixed)
 {
     for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < n; i += gridDim.x * DCSG_BLOCK) {
         float nx, ny, nz;
-        const bool other = mixed && (i & 1u);
-        dcsg_finish_normal(other ? 1.0f : in[i], other ? 2.0f : dy, other ? 3.0f : dz, nx, ny, nz);
+        const bool other = (mixed & 1) && (i & 1u);
+        const float Dx = other ? 1.0f : in[i], Dy = other ? 2.0f : dy, Dz = other ? 3.0f : dz;
+        if (mixed & 2) {  // the deferred-guard form the four-points-per-lane sweep uses, with its fallback
+            DcsgNormalAcc acc = dcsg_normal_acc_init(0x3f800000u, 0x3f800000u);
+            dcsg_finish_normal_acc(Dx, Dy, Dz, nx, ny, nz, acc);
+            if (__builtin_amdgcn_ballot_w64(dcsg_normal_acc_bad(acc)) != 0ull) dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
+        } else {
+            dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
+        }
         out[3u * i] = nx, out[3u * i + 1u] = ny, out[3u * i + 2u] = nz;
     }
 }
 
-#if defined(DCSG_EXTERN_BANK) && !defined(DCSG_SET_SPEC)
+#endif  // DCSG_PART_REST (T-junction repair, test kernels)
+
+#if defined(DCSG_EXTERN_BANK) && !defined(DCSG_SET_SPEC) && defined(DCSG_PART_REST)
 // ---------------------------------------------------------------------------
 // Preview: kernel k1 (k1.cl:479-578) -- sphere tracing of the scene plus the three axis markers into a 640 x 480
 // RGB image, one thread per pixel, the build procedure through the generic interpreter.  Scene modules only (the

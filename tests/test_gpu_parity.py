@@ -305,6 +305,71 @@ def test_lattice_sweep_bit_exact(ev, oracle, name):
         assert np.array_equal(bits(gs6), bits(osc.eval_lattice(center, diameter[0], r, normals=False)[0]))
 
 
+LIGHT_DESIGNS = {
+    # standard brushes only, at most four object evaluations: what the row kernels (dcsg_sweep_rows) are generated for
+    "sphere_offset": "draw(sphere_brush, Transform.initial(np.array([0.31, -0.17, 0.08]), 0.4, -0.7, 1.1, np.array([0.9, 0.6, 0.75])))",
+    "cyl_minus_box": "draw(cylinder_brush, Transform.initial(np.array([0.0, 0.0, 0.0]), 0.0, 0.0, 0.0, np.array([1.0, 1.0, 1.0])))\n"
+                     "erase(box_brush, Transform.initial(np.array([0.2, 0.1, -0.3]), 0.7, 0.2, -0.4, np.array([0.5, 0.9, 0.4])))",
+    "three_in_group": "drawIntersection(Component(sphere_brush, Transform.initial(np.array([0.1, 0.0, 0.0]), 0.0, 0.0, 0.0, np.array([1.0, 1.0, 1.0]))), "
+                      "Component(box_brush, Transform.initial(np.array([0.0, 0.05, 0.0]), 0.3, 0.5, 0.1, np.array([0.8, 0.8, 0.8]))), "
+                      "Component(cylinder_brush, Transform.initial(np.array([0.0, 0.0, 0.1]), 1.2, -0.4, 0.6, np.array([0.7, 1.3, 0.7]))), "
+                      "transform=Transform.initial(np.array([0.05, -0.02, 0.03]), 0.2, 0.1, -0.3, np.array([1.1, 0.9, 1.0])))",
+}
+
+
+@pytest.mark.parametrize("name", ["sphere"] + sorted(LIGHT_DESIGNS))
+def test_row_sweep_bit_exact(ev, oracle, name, tmp_path, monkeypatch):
+    """Dense sweeps of store-bound scenes take the row kernels (a lane owns four consecutive lattice points, square-root
+    and normalisation guards tested once per pass, 16-byte stores) when a row holds at least 256 points.  Whole lattices
+    at 257 points per row against the oracle, bit for bit: SDF + normals, SDF only, Z slabs, a box centred on the
+    scene's symmetry planes (gradient components exactly zero: the merged guard fails and the pass is recomputed through
+    the guarded code) and one that is not, the rows' remainder column; then planes of the 513^3 lattice."""
+    from designcsg_amd.run import run_design
+    if name == "sphere":
+        load(ev, name)
+        osc = oracle.Scene.from_dir(scene_dir(name))
+    else:
+        script = tmp_path / "design.py"
+        script.write_text("from DesignCSG import *\nimport numpy as np\n" + LIGHT_DESIGNS[name] +
+                          "\nsetExportConfig(2.0, 3, 5, 6, np.pi / 4, 6, 16, 512, 4096)\ncommit()\n")
+        wd = run_design(str(script), str(tmp_path / "wd"))
+        assert ev.build_from_dir(wd)[0] == 0
+        osc = oracle.Scene.from_dir(wd)
+    info = ev.scene_info()
+    assert info["interpreter"] == 3, info      # per-scene specialised code
+    center, diameter, _ = osc.estimate_bounding_box(10.0)
+    boxes = [(center, diameter[0]), ([center[0] + 0.0131, center[1] - 0.0077, center[2] + 0.0253], diameter[0] * 1.037)]
+    for c, d in boxes:
+        ws, wn = osc.eval_lattice(c, d, 256)
+        gs, gn = ev.eval_lattice(c, d, 256)
+        assert np.array_equal(bits(gs), bits(ws))
+        assert np.array_equal(bits(gn), bits(wn))
+        gs2, _ = ev.eval_lattice(c, d, 256, normals=False)
+        assert np.array_equal(bits(gs2), bits(ws))
+        gs3, gn3 = ev.eval_lattice(c, d, 256, z0=100, z1=131)
+        assert np.array_equal(bits(gs3), bits(ws[100:131])) and np.array_equal(bits(gn3), bits(wn[100:131]))
+        gs4, _ = ev.eval_lattice(c, d, 256, z0=255, z1=257, normals=False)
+        assert np.array_equal(bits(gs4), bits(ws[255:257]))
+    # the flat form of the same sweeps gives the same bits (row kernels off: a different scene module)
+    monkeypatch.setenv("DCSG_NO_ROW4", "1")
+    if name == "sphere":
+        load(ev, name)
+    else:
+        assert ev.build_from_dir(wd)[0] == 0
+    fs, fn = ev.eval_lattice(boxes[1][0], boxes[1][1], 256)
+    assert np.array_equal(bits(fs), bits(gs)) and np.array_equal(bits(fn), bits(gn))
+    monkeypatch.delenv("DCSG_NO_ROW4")
+    if name == "sphere":
+        load(ev, name)
+    else:
+        assert ev.build_from_dir(wd)[0] == 0
+    # 513 points per row (two segments + one remainder point): the planes around the middle and the last ones
+    for z0, z1 in ((250, 262), (509, 513)):
+        ws, wn = osc.eval_lattice(center, diameter[0], 512, z0, z1)
+        gs, gn = ev.eval_lattice(center, diameter[0], 512, z0=z0, z1=z1)
+        assert np.array_equal(bits(gs), bits(ws)) and np.array_equal(bits(gn), bits(wn))
+
+
 GOLD_BBOX = {  # SURVEY.md 8(a-13), 8(c): centre, diameter, interior points
     "sphere": ([0.0, 0.0, 0.0], 5.3515625, 1376312),
     "design2": ([0.0, -0.0390625, 0.0], 9.3359375, 692566),
@@ -583,6 +648,51 @@ def test_normal_all_float_inputs(ev, module):
                     w, g = want[k], got[:, k]
                     same = (w.view(torch.int32) == g.view(torch.int32)) | (torch.isnan(w) & torch.isnan(g))
                     assert bool(same.all()), (hex(c), mixed, k, int((~same).sum()))
+
+
+@pytest.mark.parametrize("module", ["builtin", "scene"])
+def test_normal_zero_components_and_deferred_guard(ev, module):
+    """(1) Gradients with exactly zero components (lattice points on a symmetry plane of the scene) stay on normalize's
+    fast path: +0 and -0 in every position, next to ordinary lanes, against explicitly rounded double arithmetic, sign of
+    zero included.  (2) The deferred-guard form of the tail (dcsg_finish_normal_acc, what the four-points-per-lane sweep
+    runs) with its fallback, over every 16th block of 2^26 bit patterns of the first component and over the zero cases."""
+    import torch
+    if module == "scene":
+        load(ev, "design2")
+    else:
+        s = read_scene("flat256")
+        assert ev.build(s["scene.txt"], s["buildprocedure.txt"], None)[0] == 0 and not ev.scene_info()["jit"]
+    stream = torch.cuda.current_stream().cuda_stream
+    n = 1 << 22
+    out = torch.empty(3 * n, dtype=torch.float32, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.rand(n, generator=g, device="cuda") + 0.5) * torch.exp2(torch.randint(-12, 13, (n,), generator=g, device="cuda").float())
+    x = x * (torch.randint(0, 2, (n,), generator=g, device="cuda").float() * 2 - 1)
+    i = torch.arange(n, device="cuda")
+    x = torch.where(i % 4 == 0, torch.zeros_like(x), x)
+    x = torch.where(i % 4 == 1, -torch.zeros_like(x), x)
+    assert int((x.view(torch.int32) == -(1 << 31)).sum()) == n // 4     # the -0.0 lanes are really -0.0
+    for dy, dz in ((0.25, -0.5), (0.0, 3.0), (-0.0, 3.0), (2.0, 0.0), (0.0, -0.0), (0.0, 0.0), (-0.0, -0.0)):
+        for mode in (0, 2):
+            ev.debug_normal_device(x.data_ptr(), n, dy, dz, mode, out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            want = _normal_tail_torch(x, torch.full_like(x, dy), torch.full_like(x, dz))
+            got = out.view(n, 3)
+            for k in range(3):
+                w, q = want[k], got[:, k]
+                same = (w.view(torch.int32) == q.view(torch.int32)) | (torch.isnan(w) & torch.isnan(q))
+                assert bool(same.all()), (dy, dz, mode, k, int((~same).sum()))
+    chunk = 1 << 26
+    out = torch.empty(3 * chunk, dtype=torch.float32, device="cuda")
+    ref = torch.empty(3 * chunk, dtype=torch.float32, device="cuda")
+    for c in range(0, 1 << 32, chunk * 16):
+        xs = (torch.arange(c, c + chunk, dtype=torch.int64, device="cuda") - (1 << 32) * (c >= (1 << 31))).to(torch.int32).view(torch.float32)
+        for mixed in (0, 1):
+            ev.debug_normal_device(xs.data_ptr(), chunk, 0.25, -0.5, mixed, ref.data_ptr(), stream)      # guarded form: held to the
+            ev.debug_normal_device(xs.data_ptr(), chunk, 0.25, -0.5, mixed | 2, out.data_ptr(), stream)  # reference by the test above
+            torch.cuda.synchronize()
+            same = (ref.view(torch.int32) == out.view(torch.int32)) | (torch.isnan(ref) & torch.isnan(out))
+            assert bool(same.all()), (hex(c), mixed, int((~same).sum()))
 
 
 def test_normal_random_gradients(ev):

@@ -33,7 +33,8 @@ def main():
         objs = glob.glob(os.path.join(tmp, "*.hsaco"))
         if not objs:
             objs = [os.path.join(ROOT, "designcsg_amd", "_build", "dcsg_builtin.hsaco")]  # scene needs no JIT
-        txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", objs[0]], capture_output=True, text=True).stdout
+        # a scene module is two code objects (export part, rest part): look for the kernel in each
+        txt = "".join(subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", o], capture_output=True, text=True).stdout for o in objs)
     m = re.search(r"^[0-9a-f]+ <%s>:\n(.*?)(?=^[0-9a-f]+ <|\Z)" % re.escape(kernel), txt, re.S | re.M)
     if not m:
         sys.exit("kernel %s not found" % kernel)

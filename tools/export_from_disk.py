@@ -49,12 +49,13 @@ def main():
     if args.levels:
         lines[1:4] = [str(v) for v in args.levels]
     cfg = "\n".join(lines)
-    walls = []
+    walls, stages = [], []
     with tempfile.TemporaryDirectory() as tmp:
         for _ in range(1 + max(1, args.repeat)):
             t0 = time.perf_counter()
             st = ev.export(cfg, os.path.join(tmp, "o.stl"), os.path.join(tmp, "o.ply"))
             walls.append(time.perf_counter() - t0)
+            stages.append({k: round(getattr(st, "t_" + k) * 1e3, 3) for k in ("bbox", "sweep", "mesh", "project", "download", "write_stl", "write_ply", "total")})
         sizes = [os.path.getsize(os.path.join(tmp, f)) for f in ("o.stl", "o.ply")]
     prof = ev.load_profile()
     out = {"scene": os.path.basename(os.path.normpath(args.scene_dir)), "levels": [int(v) for v in lines[1:4]],
@@ -64,6 +65,7 @@ def main():
            "read_files_and_load_scene_s": round(t_load, 4), "first_export_s": round(walls[0], 4),
            "steady_export_s": round(min(walls[1:]), 4),
            "disk_to_files_s": round(t_load + walls[0], 4), "with_context_s": round(t_create + t_load + walls[0], 4),
+           "first_export_stages_ms": stages[0], "steady_export_stages_ms": stages[walls.index(min(walls[1:]))],
            "create_ms": prof["create"], "load_scene_ms": prof["load_scene"]}
     print(json.dumps(out))
     ev.close()
