@@ -28,6 +28,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+# Ceiling for VALU issue: the vendor's FP32 vector peak (MI355X_MICROARCH.md: 157.3 TFLOP/s = 256 CUs x 4 SIMD-32 x one
+# wave64 v_fma_f32 per 2 cycles x 2.4 GHz) as wave64 instructions per second.  Rounds 1-2 divided by a MEASURED v_fma rate
+# (8.3e11/s), which a real kernel then exceeded (Design2: "fraction" 1.18): the chip holds different clocks under
+# different instruction mixes, so only the fixed figure is a ceiling.
+VALU_PEAK_WAVE_INSTR_PER_S = 157.3e12 / 2 / 64
 BYTES_PER_POINT = 16   # 4 B SDF + 12 B normal written, nothing read
 
 WORKLOADS = {
@@ -90,8 +95,8 @@ def cpu_baseline(scene_dir, center, diameter, res, budget_s=15.0):
 
 # kernel that a fused SDF+normal sweep launches, by interpreter variant (dcsg_api.cpp: sweep_device); the SDF-only
 # sweep launches the `_d` instantiation of the same kernel
-KERNEL_VARIANT = {0: "dcsg_sweep_f", 1: "dcsg_sweep_s4_f", 2: "dcsg_sweep_s8_f", 3: "dcsg_sweep_sp_f", 4: "dcsg_sweep_c4"}
-SDF_ONLY_KERNEL = {0: "dcsg_sweep_d", 1: "dcsg_sweep_s4_d", 2: "dcsg_sweep_s8_d", 3: "dcsg_sweep_sp_d", 4: "dcsg_sweep_c4"}
+KERNEL_VARIANT = {0: "dcsg_sweep_f", 1: "dcsg_sweep_s4_f", 2: "dcsg_sweep_s8_f", 3: "dcsg_sweep_sp_f", 4: "dcsg_sweep_c4_f"}
+SDF_ONLY_KERNEL = {0: "dcsg_sweep_d", 1: "dcsg_sweep_s4_d", 2: "dcsg_sweep_s8_d", 3: "dcsg_sweep_sp_d", 4: "dcsg_sweep_c4_d"}
 
 
 def time_sweeps(ev, center, diameter, res, reps=10, settle_s=0.15):
@@ -116,18 +121,19 @@ def time_sweeps(ev, center, diameter, res, reps=10, settle_s=0.15):
                 rc = launch()
                 if rc:
                     _lib.check(h, rc)
+                if time.perf_counter() > t_end + 0.5:    # sweeps of tens of milliseconds (Design2 at 1024^3)
+                    break
             torch.cuda.synchronize()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        reg = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         for i in range(reps + 2):
-            if i >= 2:
-                evs[i - 2][0].record(stream)
+            if i == 2:
+                reg[0].record(stream)
             rc = launch()
             if rc:
                 _lib.check(h, rc)
-            if i >= 2:
-                evs[i - 2][1].record(stream)
+        reg[1].record(stream)
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in evs) / reps   # device time per launch (an event pair around each)
+        ms = reg[0].elapsed_time(reg[1]) / reps   # device time per launch: events around the region of `reps` launches
         bytes_ = (16 if nptr else 4) * n1 ** 3
         out[key] = {"kernel_ms": round(ms, 4), "GB_per_s": round(bytes_ / (ms * 1e-3) / 1e9, 1),
                     "frac_of_hbm_peak": round(bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -197,7 +203,7 @@ def export_wall_clock(ev=None):
 
 
 def profiled_traffic(kernel, workload, numerics="exact"):
-    """HBM bytes per launch of `kernel` from the committed PMC summaries (profiles/<tag>_pmc_summary.json:
+    """HBM bytes and VALU instructions per SWEEP (= per launch unless the lattice needs several launches) of `kernel` from the committed PMC summaries (profiles/<tag>_pmc_summary.json:
     separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this same command, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950), taken from the newest profile of the same workload."""
     import glob
@@ -211,9 +217,62 @@ def profiled_traffic(kernel, workload, numerics="exact"):
             continue
         if b.get("config", {}).get("workload") == workload and b.get("config", {}).get("numerics", "exact") == numerics \
                 and kernel in pmc and "hbm_bytes_per_launch" in pmc[kernel]:
-            best = (pmc[kernel]["hbm_bytes_per_launch"]["total"], "profiles/" + os.path.basename(f),
-                    pmc[kernel]["counters_mean_per_launch"].get("SQ_INSTS_VALU"))
+            lps = pmc[kernel].get("launches_per_sweep", 1)
+            valu = pmc[kernel]["counters_mean_per_launch"].get("SQ_INSTS_VALU")
+            best = (pmc[kernel].get("hbm_bytes_per_sweep", pmc[kernel]["hbm_bytes_per_launch"])["total"], "profiles/" + os.path.basename(f),
+                    valu * lps if valu else None)
     return best
+
+
+def profiled_valu_per_point(kernel, scene):
+    """VALU wave64 instructions per lattice point of `kernel` on `scene`, from the newest committed PMC summary of a bench
+    run on that scene (profiles/<tag>_pmc_summary.json + <tag>_bench.json); None when there is none."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        tag = os.path.basename(f)[:-len("_pmc_summary.json")]
+        try:
+            b = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench.json")))
+            pmc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        cfg = b.get("config", {})
+        if cfg.get("workload", "").startswith(scene + " scene") and cfg.get("numerics", "exact") == "exact" and kernel in pmc:
+            v = pmc[kernel]["counters_mean_per_launch"].get("SQ_INSTS_VALU")
+            pts = cfg.get("lattice_points")
+            if v and pts:
+                # counters are means per LAUNCH; a sweep of more than 0xf0000000 points is several launches
+                best = (v * max(1, cfg.get("launches_per_sweep", 1)) * 64.0 / pts, "profiles/" + os.path.basename(f))
+    return best
+
+
+def valu_issue(kernel_ms, lattice_points, valu_per_point, source):
+    rate = valu_per_point * lattice_points / 64.0 / (kernel_ms * 1e-3)
+    return {"valu_per_lattice_point": round(valu_per_point, 1), "achieved_wave_instr_per_s": round(rate, 0),
+            "peak_wave_instr_per_s": round(VALU_PEAK_WAVE_INSTR_PER_S, 0), "peak_source": "vendor FP32 vector peak 157.3 TFLOP/s / 128",
+            "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4), "instruction_count_source": source}
+
+
+def design2_sweeps(device):
+    """N=1 only, outside the timed region: the scene BASELINE.json's export target names (Design2: one evaluation = 63 boxes
+    + a disc, arithmetic-bound) swept densely at 512^3 and 1024^3 -- kernel time, fraction of the HBM peak, and VALU issue
+    rate against the fixed ceiling (instruction counts per lattice point from the committed PMC profile of this scene)."""
+    from designcsg_amd.evaluator import Evaluator
+    scene, _, center, diameter = WORKLOADS["design2_512"]
+    ev = Evaluator(device)
+    assert ev.build_from_dir(os.path.join(ROOT, "tests", "golden", "scenes", scene))[0] == 0
+    out = {}
+    for key, res, reps in (("design2_512", 512, 5), ("design2_1024", 1024, 3)):
+        t = time_sweeps(ev, center, diameter, res, reps=reps, settle_s=0.1)
+        n1 = res + 1
+        for form, kern in (("fused", "dcsg_sweep_sp_f"), ("sdf_only", "dcsg_sweep_sp_d")):
+            t[form]["kernel"] = kern
+            p = profiled_valu_per_point(kern, scene)
+            if p:
+                t[form]["valu_issue"] = valu_issue(t[form]["kernel_ms"], n1 ** 3, p[0], p[1])
+        out[key] = dict(t, lattice_points=n1 ** 3, numerics="exact")
+    ev.close()
+    return out
 
 
 def main():
@@ -396,11 +455,14 @@ def main():
     barrier()
     # kernel time, live: device events on the stream the sweep is launched on
     k_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     t0 = time.perf_counter()
+    region[0].record(stream)
     for i in range(args.steps):
         k_ev[i][0].record(stream)
         step()
         k_ev[i][1].record(stream)
+    region[1].record(stream)
     barrier()
     dt = time.perf_counter() - t0
     halo_ok = None
@@ -429,7 +491,10 @@ def main():
         reps = max(5, args.steps)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         lead = 2 + (64 if args.settle_s > 0 else 0)   # the timed loop above has just ended: a short lead-in is enough
+        reg = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         for i in range(reps + lead):
+            if i == lead:
+                reg[0].record(stream)
             if i >= lead:
                 evs[i - lead][0].record(stream)
             rc = L.dcsg_sweep_lattice_device(h, c3, d3, res, lo, own_hi, C.c_void_p(sdf.data_ptr()), None, sp)
@@ -437,11 +502,13 @@ def main():
                 _lib.check(h, rc)
             if i >= lead:
                 evs[i - lead][1].record(stream)
+        reg[1].record(stream)
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in evs) / reps   # per launch, as the headline kernel's time above
+        ms_pairs = sum(a.elapsed_time(b) for a, b in evs) / reps
+        ms = reg[0].elapsed_time(reg[1]) / reps   # region / launches, as the headline kernel's time above
         gbs = 4 * (own_hi - lo) * plane / (ms * 1e-3) / 1e9
         sdf_only = {"kernel": SDF_ONLY_KERNEL.get(ev.scene_info()["interpreter"], KERNEL_VARIANT[ev.scene_info()["interpreter"]]),
-                    "kernel_ms": round(ms, 4), "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                    "kernel_ms": round(ms, 4), "kernel_ms_event_pairs": round(ms_pairs, 4), "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "Mvoxels_per_s": round(res ** 3 / (ms * 1e-3) / 1e6, 1),
                     "algorithmic_bytes_per_launch": 4 * (own_hi - lo) * plane}
@@ -464,7 +531,13 @@ def main():
                     % (scene, n1, res, center, diameter))
         ms_per_step = dt / args.steps * 1e3
         value = total_voxels * args.steps / dt / 1e6
-        kernel_ms = sum(a.elapsed_time(b) for a, b in k_ev) / args.steps
+        # The kernel's average launch duration from HIP events over the timed region: one event before the K steps, one
+        # after, on the launch stream (N = 1: a step is exactly one launch of the kernel, so region / K is what rocprofv3's
+        # average duration is compared with; it still includes the gaps between launches).  An event PAIR around every
+        # launch -- rounds 1-2's figure -- reads 2-4 % higher on a 0.1-0.5 ms kernel (the events' own turnaround) and is
+        # kept next to it as kernel_ms_event_pairs.  N > 1: a step is several launches plus the exchange; pairs are used.
+        pairs_ms = sum(a.elapsed_time(b) for a, b in k_ev) / args.steps
+        kernel_ms = region[0].elapsed_time(region[1]) / args.steps if world == 1 else pairs_ms
         own_points = (own_hi - lo) * plane
         achieved = BYTES_PER_POINT * own_points / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -477,12 +550,14 @@ def main():
                        "parallelism": ("z-slab x%d: %d stacked %d^3-voxel boxes, boundary plane over RCCL" % (world, world, res)
                                        if weak else "z-slab x%d of one %d^3-voxel lattice, halo plane over RCCL" % (world, res)),
                        "lattice_points": (world * res + 1) * plane if weak else n1 ** 3,
+                       "launches_per_sweep": -(-(own_hi - lo) // max(1, 0xf0000000 // plane)),
                        "comm_backend": comm["backend"], "rccl_ranks": comm["ranks_seen"] if comm["backend"] == "nccl" else None,
                        "ranks_seen_by_all_reduce": comm["ranks_seen"], "halo_verified": halo_ok},
             "from_idle": from_idle,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
+                         "kernel": kernel, "kernel_ms": round(kernel_ms, 4), "kernel_ms_event_pairs": round(pairs_ms, 4),
+                         "kernel_ms_method": "HIP events around the timed region / K launches" if world == 1 else "event pair per step",
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT * own_points},
         }
         if single:
@@ -495,20 +570,12 @@ def main():
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_source"] = tr[1]
             if tr[2]:
-                # what actually bounds the kernel: wave64 VALU instructions issued per launch (PMC,
-                # same profile) against the issue rate of plain f32 VALU instructions MEASURED on this chip
-                # (tools/pk_rate_probe.hip, profiles/r02_pk_rate_probe.txt: v_fma_f32 8.27e11, v_mul_f32 8.55e11
-                # wave-instructions/s over 256 CUs; v_sqrt_f32 3.0e11, compare + select 6.7e11, v_mul_f64 4.5e11 -- the
-                # kernel's mix of those prices the exact sweep at 0.56 ms)
-                peak = 8.27e11
-                rate = tr[2] / (kernel_ms * 1e-3)
-                out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": tr[2],
-                                                 "per_lattice_point": round(tr[2] * 64 / own_points, 1),
-                                                 "achieved_per_s": round(rate, 0), "peak_per_s": peak,
-                                                 "peak_source": "measured v_fma_f32 issue rate (profiles/r02_pk_rate_probe.txt)",
-                                                 "frac": round(rate / peak, 4)}
+                # VALU issue: wave64 VALU instructions issued per launch (PMC, same profile) against
+                # the fixed ceiling above
+                out["roofline"]["valu_issue"] = valu_issue(kernel_ms, own_points, tr[2] * 64.0 / own_points, tr[1])
         if world == 1 and not args.no_secondary:
             out["secondary_sweeps"] = secondary_sweeps(scene_dir, local_rank, center, diameter, res)
+            out["secondary_sweeps"].update(design2_sweeps(local_rank))
         if world == 1 and not args.no_export:
             out["export_wall_clock"] = export_wall_clock()
         if world == 1 and not args.no_cpu_baseline:

@@ -42,7 +42,7 @@ struct Kernels {
     hipFunction_t sweep[5] = {}, eval_points[5] = {}, bbox[5] = {}, project[5] = {};
     hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr, test_normal = nullptr;
     hipFunction_t set_ad_rest = nullptr;  // the rest part of a scene module has its own `arbitrary_data` pointer
-    hipFunction_t sweep_d[4] = {}, sweep_f[4] = {};  // sweep[v] with the outputs fixed at compile time: SDF only / SDF + normals
+    hipFunction_t sweep_d[5] = {}, sweep_f[5] = {};  // sweep[v] with the outputs fixed at compile time: SDF only / SDF + normals
     hipFunction_t sweep_nodes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // node-wise sweep per variant
     hipFunction_t dd_insert = nullptr, dd_resolve = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
     hipFunction_t rt_mark = nullptr, rt_count = nullptr, rt_emit = nullptr;  // opt-in retopologize
@@ -205,6 +205,8 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind, int part = 
         if (t.in_export ? exp : rest) HIPCHK(c, hipModuleGetFunction(t.f, mod, t.name));
     if (kind == 0) {
         HIPCHK(c, hipModuleGetFunction(&k.sweep[4], mod, "dcsg_sweep_c4"));
+        HIPCHK(c, hipModuleGetFunction(&k.sweep_d[4], mod, "dcsg_sweep_c4_d"));
+        HIPCHK(c, hipModuleGetFunction(&k.sweep_f[4], mod, "dcsg_sweep_c4_f"));
         HIPCHK(c, hipModuleGetFunction(&k.sweep_nodes[4], mod, "dcsg_sweep_nodes_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.bbox[4], mod, "dcsg_bbox_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.project[4], mod, "dcsg_project_c4"));
@@ -410,7 +412,7 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     planes_per = planes_per < 1 ? 1 : planes_per;
     // kernels with the outputs fixed at compile time where they exist (SDF only / SDF + normals)
     hipFunction_t fn = c->k->sweep[c->variant];
-    if (c->variant < 4 && d_sdf) fn = d_nrm ? c->k->sweep_f[c->variant] : c->k->sweep_d[c->variant];
+    if (d_sdf) fn = d_nrm ? c->k->sweep_f[c->variant] : c->k->sweep_d[c->variant];
     // per-axis coordinate tables behind the scene's LDS area (kernels.hip, "Wave-level lattice indexing"); a lattice
     // too large for them (or with rows shorter than a wave) takes the per-lane index path
     size_t lds = (c->scene.lds_bytes() + 15) & ~(size_t)15;
@@ -439,6 +441,12 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
         if (!neg_zero) flags |= DCSG_SWEEP_ROWS;
     }
     if (!getenv("DCSG_NO_MULTIPASS")) flags |= DCSG_SWEEP_MULTIPASS;
+    {   // DCSG_SWEEP_FORM = run4 | merged (A/B builds with -DDCSG_SWEEP_FORMS only; the product has the plain form alone)
+        const char* form = getenv("DCSG_SWEEP_FORM");
+        const std::string f = form ? form : "plain";
+        if (f == "run4") flags |= DCSG_SWEEP_RUN4;
+        else if (f == "merged") flags |= DCSG_SWEEP_MERGED;
+    }
     // diagnostic: unused LDS per block, to hold fewer blocks on a CU (occupancy experiments, tools/ab_sweep.py)
     static const size_t lds_pad = getenv("DCSG_SWEEP_LDS_PAD") ? (size_t)atol(getenv("DCSG_SWEEP_LDS_PAD")) : 0;
     if (lds + lds_pad <= c->max_lds) lds += lds_pad;

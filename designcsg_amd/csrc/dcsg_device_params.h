@@ -11,6 +11,11 @@
 #define DCSG_SWEEP_ROWS 1u
 /* bit 1 = the stack interpreters may serve several 64-point passes with one interpretation of the program */
 #define DCSG_SWEEP_MULTIPASS 2u
+/* bits 2, 3: which form the dense sweep of a store-bound scene takes (standard brushes, <= 4 object evaluations): four
+ * points per lane (dcsg_run4), or one point per lane with one merged guard per point (dcsg_stencil_spec_merged); neither:
+ * one point per lane, every square root with its own guard */
+#define DCSG_SWEEP_RUN4 4u
+#define DCSG_SWEEP_MERGED 8u
 
 struct DcsgLattice {  // ISV3D64 geometry, ISV.hpp:91-109
     float base[3];    // center - 0.5f*diameters   (ISV.hpp:104)

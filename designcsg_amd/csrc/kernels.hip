@@ -187,6 +187,9 @@ extern "C" __device__ dcsg_cl_float8 dcsg_spec_row4_d(dcsg_cl_float4 x, float y,
 // the same with every point's own y and z (a run that crosses a row end)
 extern "C" __device__ dcsg_cl_float32 dcsg_spec_row4g(dcsg_cl_float4 x, dcsg_cl_float4 y, dcsg_cl_float4 z);
 extern "C" __device__ dcsg_cl_float8 dcsg_spec_row4g_d(dcsg_cl_float4 x, dcsg_cl_float4 y, dcsg_cl_float4 z);
+// dcsg_spec_eval7 with the standard brushes inline and the deferred guard: elements 0..6 the values, 8 / 9 the two words
+typedef float dcsg_cl_float16 __attribute__((ext_vector_type(16)));
+extern "C" __device__ dcsg_cl_float16 dcsg_spec_eval7a(dcsg_cl_float8 px, dcsg_cl_float8 py, dcsg_cl_float8 pz);
 extern "C" __device__ int dcsg_spec_row4_ok();
 #define DCSG_HAVE_SPEC 1
 #endif
@@ -1051,6 +1054,38 @@ __device__ __forceinline__ void dcsg_stencil_spec(float x, float y, float z, boo
 }
 #endif
 
+#if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
+// MEASURED AND NOT KEPT (round 3; DCSG_SWEEP_FORM=merged in a -DDCSG_SWEEP_FORMS build): 136 instead of 146 VALU
+// instructions per lattice point, 60 % instead of 76 % VALU utilisation, 6 % slower.
+// dcsg_stencil_spec<true> (SDF + normal) for scenes of standard brushes on a lattice without a -0.0 coordinate (the host's
+// DCSG_SWEEP_ROWS check): the seven square roots of the brushes and the normalisation run in one basic block, their
+// operand tests merged into one ballot per point (dcsg_spec_eval7a, dcsg_finish_normal_acc) instead of eight
+// compare-and-branch pairs; a wave that fails the test recomputes through the guarded code.  Same bits.
+__device__ __forceinline__ void dcsg_stencil_spec_merged(float x, float y, float z, float& sdf, float& nx, float& ny, float& nz)
+{
+    const float e = (float)K2_NORMAL_EPSILON;
+    float xp = x + e, xm = x - e, yp = y + e, ym = y - e, zp = z + e, zm = z - e;
+    dcsg_cl_float8 px = {x, xp, xm, x, x, x, x, 0.0f};
+    dcsg_cl_float8 py = {y, y, y, yp, ym, y, y, 0.0f};
+    dcsg_cl_float8 pz = {z, z, z, z, z, zp, zm, 0.0f};
+    dcsg_cl_float16 o = dcsg_spec_eval7a(px, py, pz);
+    DcsgNormalAcc acc = dcsg_normal_acc_init(__float_as_uint(o[8]), __float_as_uint(o[9]));
+    sdf = o[0];
+    dcsg_finish_normal_acc(o[1] - o[2], o[3] - o[4], o[5] - o[6], nx, ny, nz, acc);
+#ifdef DCSG_SCHED_SPREAD_TRANS
+    // experiment: ask the scheduler to spread the nine quarter-rate instructions (7 + 1 rsq, 1 rcp) over the block, each
+    // followed by DCSG_SCHED_SPREAD_TRANS plain VALU instructions, instead of bunching them
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);                        // 1 TRANS
+        __builtin_amdgcn_sched_group_barrier(0x2, DCSG_SCHED_SPREAD_TRANS, 0);    // n VALU
+    }
+#endif
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(dcsg_normal_acc_bad(acc)) != 0ull, 0))
+        dcsg_stencil_spec<true>(x, y, z, true, true, sdf, nx, ny, nz);
+}
+#endif
+
 // ISV3D64::getPoint, ISV.hpp:103-109
 __device__ __forceinline__ float dcsg_lattice_coord(const DcsgLattice& L, int axis, int i)
 {
@@ -1153,8 +1188,10 @@ __device__ __forceinline__ void dcsg_wave_advance(unsigned int n1, unsigned int&
 #define DCSG_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #endif
 
-#ifdef DCSG_HAVE_SPEC
+#if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
 // ---------------------------------------------------------------------------
+// MEASURED AND NOT KEPT (round 3): compiled only with -DDCSG_SWEEP_FORMS (tools/make_ab_tree.sh), selected at run time by
+// DCSG_SWEEP_FORM=run4.  Fewer instructions, more time: profiles/r03_ab_forms.txt, r03_pmcq_clk_*.txt, DESIGN.md.
 // Four lattice points per lane for store-bound scenes (standard brushes, at most four object evaluations:
 // dcsg_spec_row4_ok()): in a run of 256 consecutive points a LANE OWNS the points lane, lane + 64, lane + 128, lane + 192,
 // i.e. its share of each of the run's four 64-point passes, so that the stores keep the flat kernel's shape (per
@@ -1239,15 +1276,26 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                                                 float* __restrict__ sdf_out, float* __restrict__ nrm_out, int axes_off,
                                                 unsigned int flags)
 {
-    SceneLds s = dcsg_stage_scene(blob, n_vec4);
-    const float* ax = dcsg_stage_axes(L, axes_off);
-    const bool want_sdf = MODE == 0 ? sdf_out != nullptr : true;
-    const bool want_nrm = MODE == 0 ? nrm_out != nullptr : MODE == 3;
     const unsigned int n1 = (unsigned int)L.res + 1u;
     const unsigned int tile_points = DCSG_RUN * (DCSG_BLOCK / DCSG_WAVE);
     const unsigned int tiles = (n_points + tile_points - 1u) / tile_points;
     const unsigned int lane = threadIdx.x & (DCSG_WAVE - 1u);
     const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / DCSG_WAVE));
+    // per-scene specialised code has the scene in its instructions: no tables to stage (a block's start-up is then the
+    // axis tables alone -- the blob's global loads and their barrier cost every block about a microsecond of latency,
+    // eight times per CU in a 0.1 ms SDF-only sweep: sphere 513^3 0.108 -> 0.104 ms).  Dropping the axis tables as well
+    // (positions from dcsg_lattice_coord per point, no LDS, no barrier, finer grids) was measured and not kept: 0.110 ms
+    // at 513^3 and 0.82 against 0.75 ms at 1025^3 (profiles/r03_ab_notables.txt).
+    SceneLds s = K < 0 ? SceneLds{} : dcsg_stage_scene(blob, n_vec4);
+    const float* ax = dcsg_stage_axes(L, axes_off);
+    const bool want_sdf = MODE == 0 ? sdf_out != nullptr : true;
+    const bool want_nrm = MODE == 0 ? nrm_out != nullptr : MODE == 3;
+#if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
+    // one merged guard per lattice point (dcsg_stencil_spec_merged): standard brushes, no -0.0 coordinate on the lattice
+    const bool merged = K < 0 && (flags & DCSG_SWEEP_ROWS) && (flags & DCSG_SWEEP_MERGED) && dcsg_spec_row4_ok();
+#else
+    const bool merged = false;
+#endif
     for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const unsigned int local0 = tile * tile_points + wave * DCSG_RUN;  // wave-uniform from here ...
         if (local0 >= n_points) continue;
@@ -1261,10 +1309,11 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             iy0 = t0 - iz0 * n1;
             plane0 = iz0 + (unsigned int)z0;                                // ... to here
         }
-        // Stack interpreters: ONE interpretation of the program serves several of the run's four 64-point passes -- the
-        // step decode (LDS record, readfirstlane, opcode / brush / depth branches: scalar work, ~35 instructions per step)
-        // is paid per 256 points (SDF only: the lane's point of each of the four passes) or per 128 (SDF + normals: two
-        // passes x seven stencil points) instead of per 64.  Same arithmetic per point: same bits.
+        // Stack interpreters, SDF only: ONE interpretation of the program serves the run's four 64-point passes (the lane's
+        // point of each) -- the step decode (LDS record, readfirstlane, opcode / brush / depth branches: scalar work,
+        // ~35 instructions per step) is paid per 256 points instead of per 64: sphere 513^3 0.546 -> 0.234 ms.  Same
+        // arithmetic per point: same bits.  (SDF + normals, two passes x seven stencil points per interpretation: the
+        // kernel's registers go from 95 to 184 and the sweep from 1.04 to 1.45 ms -- measured, not kept.)
         if (K > 0 && MODE == 1 && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_MULTIPASS)) {
             float px[4], py[4], pz[4], o[4];
 #pragma unroll
@@ -1278,38 +1327,9 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             for (int j = 0; j < 4; j++) DCSG_STREAM_STORE(o[j], sdf_out + idx0 + lane + 64 * j);
             continue;
         }
-        if (K > 0 && MODE == 3 && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_ROWS) && (flags & DCSG_SWEEP_MULTIPASS)) {  // no -0.0 coordinate
-            const float e = (float)K2_NORMAL_EPSILON;
-#pragma unroll 1
-            for (int half = 0; half < 2; half++) {
-                float px[14], py[14], pz[14], o[14];
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
-                    dcsg_wave_advance(n1, ix0, iy0, plane0);
-                    const float xp = w.x + e, xm = w.x - e, yp = w.y + e, ym = w.y - e, zp = w.z + e, zm = w.z - e;
-                    const float qx[7] = {w.x, xp, xm, w.x, w.x, w.x, w.x}, qy[7] = {w.y, w.y, w.y, yp, ym, w.y, w.y},
-                                qz[7] = {w.z, w.z, w.z, w.z, w.z, zp, zm};
-#pragma unroll
-                    for (int k = 0; k < 7; k++) px[7 * j + k] = qx[k], py[7 * j + k] = qy[k], pz[7 * j + k] = qz[k];
-                }
-                dcsg_interp<(K <= 0 ? 4 : K), 14>(s, px, py, pz, o);
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    float nx, ny, nz;
-                    dcsg_finish_normal(o[7 * j + 1] - o[7 * j + 2], o[7 * j + 3] - o[7 * j + 4], o[7 * j + 5] - o[7 * j + 6], nx, ny, nz);
-                    const unsigned int at = idx0 + lane + 64u * (unsigned int)(2 * half + j);
-                    DCSG_STREAM_STORE(o[7 * j], sdf_out + at);
-                    float* q = nrm_out + (size_t)at * 3;
-                    DCSG_STREAM_STORE(nx, q);
-                    DCSG_STREAM_STORE(ny, q + 1);
-                    DCSG_STREAM_STORE(nz, q + 2);
-                }
-            }
-            continue;
-        }
-#ifdef DCSG_HAVE_SPEC
-        if (K < 0 && (MODE == 1 || MODE == 3) && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_ROWS) && dcsg_spec_row4_ok()) {
+#if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
+        if (K < 0 && (MODE == 1 || MODE == 3) && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_ROWS) && (flags & DCSG_SWEEP_RUN4) &&
+            dcsg_spec_row4_ok()) {
             // four points per lane (dcsg_run4): the lane's share of each of the run's four passes
             dcsg_cl_float4 x4, y4, z4;
 #ifdef DCSG_EXPERIMENT_ALL_IN_ROW  // timing experiment only (wrong values at row ends): every run through the shared-y/z code
@@ -1335,12 +1355,18 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             dcsg_run4<MODE>(x4, y4, z4, in_row, sdf_out + idx0 + lane, MODE == 3 ? nrm_out + (size_t)idx0 * 3 + lane * 3u : nullptr);
             continue;
         }
+#endif
+#ifdef DCSG_HAVE_SPEC
         // Small scenes: passes that lie inside one lattice row share y and z, so everything the seven stencil evaluations
         // derive from those two alone is computed once for the passes of a row segment (loop-invariant code motion: same
         // operations, same bits), and the per-pass row tests disappear.
         auto row_pass = [&](const float* xrow, float y, float z, unsigned int k) {
             float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
-            dcsg_stencil_spec<true>(xrow[k * DCSG_WAVE], y, z, true, MODE == 3, sd, nx, ny, nz);
+#ifdef DCSG_SWEEP_FORMS
+            if (MODE == 3 && merged) dcsg_stencil_spec_merged(xrow[k * DCSG_WAVE], y, z, sd, nx, ny, nz);
+            else
+#endif
+                dcsg_stencil_spec<true>(xrow[k * DCSG_WAVE], y, z, true, MODE == 3, sd, nx, ny, nz);
             __builtin_nontemporal_store(sd, (sdf_out + idx0) + lane + k * DCSG_WAVE);
             if (MODE == 3) {
                 float* o = nrm_out + (size_t)idx0 * 3 + (lane + k * DCSG_WAVE) * 3u;
@@ -1382,7 +1408,11 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                 if (want_nrm) dcsg_get_normal(s, x, y, z, nx, ny, nz);
 #ifdef DCSG_HAVE_SPEC
             } else if (K < 0) {
-                dcsg_stencil_spec<true>(x, y, z, want_sdf, want_nrm, sd, nx, ny, nz);
+#ifdef DCSG_SWEEP_FORMS
+                if (MODE == 3 && merged) dcsg_stencil_spec_merged(x, y, z, sd, nx, ny, nz);
+                else
+#endif
+                    dcsg_stencil_spec<true>(x, y, z, want_sdf, want_nrm, sd, nx, ny, nz);
 #endif
             } else {
                 dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, want_sdf, want_nrm, sd, nx, ny, nz);
@@ -1442,8 +1472,11 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
     }
 }
 
+// SDF-only kernels of per-scene code (K < 0, MODE 1): at least 8 waves per SIMD, i.e. at most 64 VGPRs -- the allocator
+// otherwise lets the four unrolled passes drift to 65, one wave per SIMD less (sphere: 23 under the bound, Design2: 47,
+// no spill).  Not for SDF + normals: Design2's seven stencil evaluations of a 63-box brush spill under it.
 #define DCSG_SWEEP_KERNEL(NAME, K, MODE)                                                                            \
-    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                        \
+    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, ((K) < 0 && (MODE) == 1 ? 8 : 1))                      \
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,                     \
          unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out, int axes_off,             \
          unsigned int flags)                                                                                        \
@@ -2297,11 +2330,13 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
 // Lattice sweep with block-brick culling.  The launch covers whole planes (first = multiple of (res+1)^2).
 // A wave writes 8 rows of 8 consecutive points (32-B / 96-B segments): this kernel is for scenes whose cost
 // is hundreds of object evaluations per point, where store shape is irrelevant next to the work removed.
-extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
-dcsg_sweep_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,
-              unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out, int /*axes_off: unused*/,
-              unsigned int /*flags: unused*/)
+// MODE as in dcsg_sweep_body: 0 = outputs read off the pointers, 1 = SDF only, 3 = SDF + normals (own kernel names, so
+// that a profile never averages the 4 B/point and the 16 B/point sweep under one name)
+template <int MODE>
+__device__ __forceinline__ void dcsg_sweep_c4_body(const uint4* __restrict__ blob, int n_vec4, const DcsgLattice& L, int z0, unsigned int first,
+                                                   unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_arg)
 {
+    float* __restrict__ nrm_out = MODE == 1 ? nullptr : nrm_arg;
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     const unsigned int n1 = (unsigned int)L.res + 1u;
     const unsigned int plane = n1 * n1;
@@ -2350,6 +2385,17 @@ dcsg_sweep_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0,
         }
     }
 }
+
+#define DCSG_SWEEP_C4_KERNEL(NAME, MODE)                                                                               \
+    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                          \
+    NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first, unsigned int n_points, \
+         float* __restrict__ sdf_out, float* __restrict__ nrm_out, int /*axes_off: unused*/, unsigned int /*flags*/)   \
+    {                                                                                                                  \
+        dcsg_sweep_c4_body<MODE>(blob, n_vec4, L, z0, first, n_points, sdf_out, nrm_out);                              \
+    }
+DCSG_SWEEP_C4_KERNEL(dcsg_sweep_c4, 0)
+DCSG_SWEEP_C4_KERNEL(dcsg_sweep_c4_d, 1)
+DCSG_SWEEP_C4_KERNEL(dcsg_sweep_c4_f, 3)
 
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, double bb_eps, int* __restrict__ result)

@@ -27,7 +27,9 @@ static std::string hexf(float f)
 //             (N = 28, point 7 j + k = lattice point j, stencil point k), standard brushes written inline with the
 //             deferred square-root guard (scene_prelude.cl: dcsg_std_brush_acc);
 //         2 = row kernel, SDF only: the 4 lattice points (N = 4);
-//         3, 4 = as 1, 2 with every lattice point's own y and z (float4): a run that crosses a row end.
+//         3, 4 = as 1, 2 with every lattice point's own y and z (float4): a run that crosses a row end;
+//         5 = the N = 7 stencil points of ONE lattice point (float8 lanes, as layout 0) with the standard brushes inline
+//             and the deferred square-root guard: returns float16 (o0..o6, 0, bits of gmn, bits of gmx, 0...).
 static void emit_function(const Scene& s, bool null_brush_const, int N, bool simplify, const char* name1, std::string& out, int layout = 0)
 {
     enum {
@@ -54,6 +56,9 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
         out += "  uint gmn = 0x3f800000u, gmx = 0x3f800000u;\n";
     } else if (sdf4) {
         out += std::string(inl) + (gen ? "float8 dcsg_spec_row4g_d(float4 x, float4 y, float4 z){\n" : "float8 dcsg_spec_row4_d(float4 x, float y, float z){\n");
+        out += "  uint gmn = 0x3f800000u, gmx = 0x3f800000u;\n";
+    } else if (layout == 5) {
+        out += std::string(inl) + "float16 dcsg_spec_eval7a(float8 px, float8 py, float8 pz){\n";
         out += "  uint gmn = 0x3f800000u, gmx = 0x3f800000u;\n";
     } else if (N == 7)
         out += std::string(inl) + "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){\n";
@@ -193,6 +198,8 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
         out += "  res[28] = as_float(gmn);\n  res[29] = as_float(gmx);\n  return res;\n}\n";
     } else if (sdf4) {
         out += "  return (float8)(o0, o1, o2, o3, as_float(gmn), as_float(gmx), 0.0f, 0.0f);\n}\n";
+    } else if (layout == 5) {
+        out += "  return (float16)(o0, o1, o2, o3, o4, o5, o6, 0.0f, as_float(gmn), as_float(gmx), 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);\n}\n";
     } else if (N == 7)
         out += "  return (float8)(o0, o1, o2, o3, o4, o5, o6, 0.0f);\n}\n";
     else
@@ -204,6 +211,7 @@ static const char kRow4Stubs[] =
     "float8 dcsg_spec_row4_d(float4 x, float y, float z){ return (float8)(0.0f); }\n"
     "dcsg_float32 dcsg_spec_row4g(float4 x, float4 y, float4 z){ return (dcsg_float32)(0.0f); }\n"
     "float8 dcsg_spec_row4g_d(float4 x, float4 y, float4 z){ return (float8)(0.0f); }\n"
+    "float16 dcsg_spec_eval7a(float8 px, float8 py, float8 pz){ return (float16)(0.0f); }\n"
     "int dcsg_spec_row4_ok(void){ return 0; }\n";
 
 // OpenCL C for dcsg_spec_eval7 / dcsg_spec_eval1.  With `enable` false (or a program that is not
@@ -235,11 +243,14 @@ std::string specialised_source(const Scene& s, bool null_brush_const, bool enabl
     // Row kernels (kernels.hip, dcsg_sweep_rows): a lane owns four consecutive lattice points of one row.  Only for
     // scenes of standard brushes (`simplify`: their bodies are written inline, so that the square roots' range tests can
     // be merged) with at most four object evaluations (the dense sweeps of such a scene are store-bound).
-    if (simplify && evals <= 4 && !getenv("DCSG_NO_ROW4")) {
+    // (round 3: measured and not kept -- fewer instructions, lower VALU utilisation, more time; the evaluation is generated
+    // only for A/B builds: DCSG_SWEEP_FORMS=1 in the environment and kernels.hip built with -DDCSG_SWEEP_FORMS)
+    if (simplify && evals <= 4 && getenv("DCSG_SWEEP_FORMS") && !getenv("DCSG_NO_ROW4")) {
         emit_function(s, null_brush_const, 28, simplify, "", out, 1);
         emit_function(s, null_brush_const, 4, simplify, "", out, 2);
         emit_function(s, null_brush_const, 28, simplify, "", out, 3);
         emit_function(s, null_brush_const, 4, simplify, "", out, 4);
+        emit_function(s, null_brush_const, 7, simplify, "", out, 5);
         out += "__attribute__((always_inline)) int dcsg_spec_row4_ok(void){ return 1; }\n";
         if (rows_out) *rows_out = true;
     } else {

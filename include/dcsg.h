@@ -90,7 +90,12 @@ const char* dcsg_last_error(const dcsg_ctx* ctx);
  * scene_cl may be NULL when every brush id in scene.txt is one of the five built-ins 0..4.
  * arbitrary_data may be NULL (all zeros); n_arbitrary <= DCSG_ARBITRARY_DATA_POINTS.
  * On a brush compile error returns DCSG_ERR_BUILD with the compiler log as the error string,
- * like Evaluator::build returning (-1, log). */
+ * like Evaluator::build returning (-1, log).
+ * A scene's code comes in two code objects: the part dcsg_export launches (stage A, node-wise sweep, mesher, projection)
+ * is ready when this call returns; the rest (dense sweeps, point evaluation, T-junction repair) is loaded on first use --
+ * from the on-disk cache, or, after a cold build, from a host thread that compiles it in the background while the caller
+ * already exports (the first dcsg_eval_* / dcsg_sweep_* call then waits for that thread; a compile error of the rest
+ * surfaces there as DCSG_ERR_BUILD).  DCSG_JIT_SYNC=1 in the environment builds both parts inside this call. */
 int dcsg_load_scene(dcsg_ctx* ctx, const char* scene_txt, const char* buildprocedure_txt, const char* scene_cl,
                     const float* arbitrary_data, size_t n_arbitrary);
 /* Arithmetic of the scenes loaded AFTER this call (no reference counterpart; default DCSG_NUMERICS_EXACT).
@@ -199,7 +204,9 @@ int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* 
 #define DCSG_EXPORT_DENSE_SWEEP 16u   /* sweep the whole lattice even where the node-wise sweep would do */
 #define DCSG_EXPORT_INDEXED_PLY 4u    /* ply_path gets dcsg_write_ply_indexed instead of the reference layout */
 #define DCSG_EXPORT_STL_NORMALS 8u    /* stl_path gets dcsg_write_stl_normals instead of zero normals */
-#define DCSG_EXPORT_RETOPO 32u        /* run dcsg_retopologize between the mesher and the projection (default: identity) */
+#define DCSG_EXPORT_RETOPO 32u        /* run dcsg_retopologize between the mesher and the projection (default: identity);
+                                         whole-mesh exports only: DCSG_ERR_INVALID from dcsg_export_slab / _multi with
+                                         world > 1 (a slab sees only its own vertices, T-junctions on slab borders would stay) */
 int dcsg_export(dcsg_ctx* ctx, const char* export_config_txt, const char* stl_path, const char* ply_path,
                 unsigned flags, dcsg_export_stats* stats);
 
@@ -247,16 +254,17 @@ float dcsg_angle_q_star(float complex_surface_threshold);
 /* Diagnostic: the kernels' correctly rounded square root over a device array (exhaustive GPU test). */
 int dcsg_debug_sqrt_device(dcsg_ctx* ctx, const float* d_in, size_t n, float* d_out, void* stream);
 /* Diagnostic: the tail of get_normal (k2.cl:175-177: gradient scale in double, normalize) as the kernels compute it,
- * d_out[3i..3i+2] = normal of the gradient (d_in[i], dy, dz); mixed != 0: odd elements take (1, 2, 3) instead, so a
- * wave holds ordinary and extreme operands together (exhaustive GPU test of the float-only scale). */
+ * d_out[3i..3i+2] = normal of the gradient (d_in[i], dy, dz); mixed bit 0: odd elements take (1, 2, 3) instead, so a
+ * wave holds ordinary and extreme operands together (exhaustive GPU test of the float-only scale); bit 1: through the
+ * deferred-guard form (dcsg_finish_normal_acc) and its fallback. */
 int dcsg_debug_normal_device(dcsg_ctx* ctx, const float* d_in, size_t n, float dy, float dz, int mixed, float* d_out, void* stream);
 
 /* The compile half of Evaluator::build without a device: compiles scene_cl into the on-disk code
  * object cache (used at install time so that known scenes load without compiling).  The compiler
  * log is copied to log_out; *from_cache = 1 when the code object already existed. */
 int dcsg_jit_prebuild(const char* scene_cl, char* log_out, size_t log_cap, int* from_cache);
-/* Same for a whole scene: compiles exactly the code object dcsg_load_scene would ask for (brush text plus
- * the specialisation of its build procedure), if it needs one. */
+/* Same for a whole scene: compiles exactly the code objects dcsg_load_scene would ask for (both parts: brush text plus
+ * the specialisation of its build procedure), if it needs any. */
 int dcsg_jit_prebuild_scene(const char* scene_txt, const char* buildprocedure_txt, const char* scene_cl, char* log_out,
                             size_t log_cap, int* from_cache);
 

@@ -38,12 +38,22 @@ def main(tag):
             for c, v in counters.items():
                 o["counters_mean_per_launch"][c] = sum(v) / len(v)
                 o["dispatches"] = max(o["dispatches"], len(v))
+    # A sweep of more than 0xf0000000 lattice points is several launches of the same kernel (bench.py:
+    # config.launches_per_sweep; 1 for every workload up to 1025^3 since round 3): per-SWEEP figures are the per-launch
+    # means times that count, so that they can stand next to the algorithmic bytes of a whole sweep.
+    try:
+        lps = int(json.load(open(os.path.join(src, "stats_bench.json"))).get("config", {}).get("launches_per_sweep", 1))
+    except (OSError, ValueError):
+        lps = 1
     for k, o in out.items():
         c = o["counters_mean_per_launch"]
+        o["launches_per_sweep"] = lps if k.startswith("dcsg_sweep") else 1
         if "WRITE_SIZE" in c or "FETCH_SIZE" in c:
             w = c.get("WRITE_SIZE", 0.0) * 1024.0
             r = c.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0  # gfx950: FETCH_SIZE counts 64 B per 128-B request
             o["hbm_bytes_per_launch"] = {"written": w, "read_corrected": r, "total": w + r}
+            n = o["launches_per_sweep"]
+            o["hbm_bytes_per_sweep"] = {"written": w * n, "read_corrected": r * n, "total": (w + r) * n}
     json.dump(out, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in out.items()}, indent=1))
 

@@ -721,6 +721,45 @@ def test_normal_random_gradients(ev):
             assert bool(same.all()), (it, k, int((~same).sum()))
 
 
+def test_cold_build_exports_before_the_rest_part_is_ready(built_lib, oracle, tmp_path, monkeypatch):
+    """A scene module is two code objects (csrc/jit.hpp): a cold dcsg_load_scene compiles the export part, returns, and a
+    background host thread compiles the rest (dense sweeps, point evaluation) while the caller already exports.  The
+    export's files must be byte-identical to those of a warm load, and the rest part -- joined and loaded on first use --
+    must evaluate like the oracle.  DCSG_JIT_SYNC=1 (everything in the foreground) gives the same."""
+    from designcsg_amd.evaluator import Evaluator
+    s = read_scene("design1")
+    cfg_txt = export_config_text("design1", levels=(3, 5, 6), gd=6)
+    osc = oracle.Scene.from_dir(scene_dir("design1"))
+    pts = np.random.default_rng(3).uniform(-3, 3, (5000, 3)).astype(np.float32)
+    want = osc.eval_sdf(pts)
+    files = {}
+    for mode in ("warm", "cold", "cold_sync"):
+        monkeypatch.delenv("DCSG_JIT_NO_CACHE", raising=False)
+        monkeypatch.delenv("DCSG_JIT_SYNC", raising=False)
+        if mode != "warm":
+            monkeypatch.setenv("DCSG_JIT_NO_CACHE", "1")
+        if mode == "cold_sync":
+            monkeypatch.setenv("DCSG_JIT_SYNC", "1")
+        e = Evaluator(0)
+        try:
+            assert e.build(s["scene.txt"], s["buildprocedure.txt"], s["scene.cl"])[0] == 0
+            prof = e.load_profile()["load_scene"]
+            assert ("code_object_compiled" in prof) == (mode != "warm"), prof
+            assert ("rest_part_compiled_and_loaded" in prof) == (mode == "cold_sync"), prof
+            stl, ply = tmp_path / (mode + ".stl"), tmp_path / (mode + ".ply")
+            st = e.export(cfg_txt, str(stl), str(ply))       # needs the export part only
+            assert st.triangles > 0
+            files[mode] = (stl.read_bytes(), ply.read_bytes())
+            got = e.eval_sdf_at_points(pts)                   # needs the rest part: joins the background build
+            assert np.array_equal(bits(got), bits(want)), mode
+            gs, gn = e.eval_lattice([0.0, 0.0, 0.0], 6.0, 24)
+            ws, wn = osc.eval_lattice([0.0, 0.0, 0.0], [6.0] * 3, 24)
+            assert np.array_equal(bits(gs), bits(ws)) and np.array_equal(bits(gn), bits(wn)), mode
+        finally:
+            e.close()
+    assert files["cold"] == files["warm"] == files["cold_sync"]
+
+
 def test_set_arbitrary_data_after_build(ev, oracle):
     """Evaluator::setArbitraryData (Evaluator.cpp:213-225) on a loaded scene: the brushes see the new table."""
     s = load(ev, "ad_table")

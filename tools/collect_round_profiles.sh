@@ -5,10 +5,11 @@
 #   bash tools/collect_round_profiles.sh      (then `python profiles/summarise.py <tag>` here for every tag)
 set -o pipefail
 export TMPDIR=/tmp
-R=r02
+R=r03
 bash profiles/run_profile.sh $R > gpurun_out/p1.log 2>&1 && \
 bash profiles/run_profile.sh ${R}_sphere1024 --workload sphere1024 > gpurun_out/p1b.log 2>&1 && \
 bash profiles/run_profile.sh ${R}_design2 --workload design2_512 > gpurun_out/p2.log 2>&1 && \
+bash profiles/run_profile.sh ${R}_design2_1024 --workload design2_1024 --steps 4 > gpurun_out/p2b.log 2>&1 && \
 bash profiles/run_profile.sh ${R}_flat256 --workload flat256_512 > gpurun_out/p3.log 2>&1 && \
 bash profiles/run_profile.sh ${R}_grouped256 --workload grouped256_512 > gpurun_out/p4.log 2>&1 && \
 bash profiles/run_profile.sh ${R}_smooth256 --workload smooth256_512 > gpurun_out/p5.log 2>&1 && \
