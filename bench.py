@@ -459,9 +459,11 @@ def main():
     t0 = time.perf_counter()
     region[0].record(stream)
     for i in range(args.steps):
-        k_ev[i][0].record(stream)
+        if world > 1:
+            k_ev[i][0].record(stream)
         step()
-        k_ev[i][1].record(stream)
+        if world > 1:
+            k_ev[i][1].record(stream)
     region[1].record(stream)
     barrier()
     dt = time.perf_counter() - t0
@@ -489,26 +491,20 @@ def main():
     sdf_only = None
     if world == 1:
         reps = max(5, args.steps)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         lead = 2 + (64 if args.settle_s > 0 else 0)   # the timed loop above has just ended: a short lead-in is enough
         reg = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         for i in range(reps + lead):
             if i == lead:
                 reg[0].record(stream)
-            if i >= lead:
-                evs[i - lead][0].record(stream)
             rc = L.dcsg_sweep_lattice_device(h, c3, d3, res, lo, own_hi, C.c_void_p(sdf.data_ptr()), None, sp)
             if rc:
                 _lib.check(h, rc)
-            if i >= lead:
-                evs[i - lead][1].record(stream)
         reg[1].record(stream)
         torch.cuda.synchronize()
-        ms_pairs = sum(a.elapsed_time(b) for a, b in evs) / reps
         ms = reg[0].elapsed_time(reg[1]) / reps   # region / launches, as the headline kernel's time above
         gbs = 4 * (own_hi - lo) * plane / (ms * 1e-3) / 1e9
         sdf_only = {"kernel": SDF_ONLY_KERNEL.get(ev.scene_info()["interpreter"], KERNEL_VARIANT[ev.scene_info()["interpreter"]]),
-                    "kernel_ms": round(ms, 4), "kernel_ms_event_pairs": round(ms_pairs, 4), "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                    "kernel_ms": round(ms, 4), "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "Mvoxels_per_s": round(res ** 3 / (ms * 1e-3) / 1e6, 1),
                     "algorithmic_bytes_per_launch": 4 * (own_hi - lo) * plane}
@@ -532,12 +528,13 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_voxels * args.steps / dt / 1e6
         # The kernel's average launch duration from HIP events over the timed region: one event before the K steps, one
-        # after, on the launch stream (N = 1: a step is exactly one launch of the kernel, so region / K is what rocprofv3's
-        # average duration is compared with; it still includes the gaps between launches).  An event PAIR around every
-        # launch -- rounds 1-2's figure -- reads 2-4 % higher on a 0.1-0.5 ms kernel (the events' own turnaround) and is
-        # kept next to it as kernel_ms_event_pairs.  N > 1: a step is several launches plus the exchange; pairs are used.
-        pairs_ms = sum(a.elapsed_time(b) for a, b in k_ev) / args.steps
-        kernel_ms = region[0].elapsed_time(region[1]) / args.steps if world == 1 else pairs_ms
+        # after, on the launch stream, nothing in between (N = 1: a step is exactly one launch of the kernel, so region / K
+        # is what rocprofv3's average duration is compared with; it includes the gaps between launches).  N > 1: a step is
+        # several launches plus the exchange, timed by an event pair per step.
+        if world == 1:
+            kernel_ms = region[0].elapsed_time(region[1]) / args.steps
+        else:
+            kernel_ms = sum(a.elapsed_time(b) for a, b in k_ev) / args.steps
         own_points = (own_hi - lo) * plane
         achieved = BYTES_PER_POINT * own_points / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -556,7 +553,7 @@ def main():
             "from_idle": from_idle,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": kernel, "kernel_ms": round(kernel_ms, 4), "kernel_ms_event_pairs": round(pairs_ms, 4),
+                         "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
                          "kernel_ms_method": "HIP events around the timed region / K launches" if world == 1 else "event pair per step",
                          "algorithmic_bytes_per_launch": BYTES_PER_POINT * own_points},
         }

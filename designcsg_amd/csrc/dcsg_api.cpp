@@ -83,6 +83,8 @@ struct dcsg_ctx {
     bool scene_loaded = false, jit = false, specialised = false;
     bool light_scene = false;  // at most four evaluations of standard brushes: its sweeps are store-bound (sweep_grid)
     bool row_kernels = false;  // the scene module holds dcsg_spec_row4*: dense sweeps may take dcsg_sweep_rows
+    DcsgLattice nz_lattice;    // sweep_device: the lattice last checked for a -0.0 coordinate, and the answer
+    bool nz_valid = false, nz_result = false;
     int numerics = 0;  // DCSG_NUMERICS_EXACT / _RELAXED for the scenes loaded from now on (dcsg_set_numerics)
     bool scene_relaxed = false;
     int variant = 0;  // index into Kernels::sweep[] etc., chosen from the scene's register count
@@ -96,6 +98,8 @@ struct dcsg_ctx {
     void* h_pinned = nullptr;  // host staging for triangle downloads
     size_t h_pinned_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t sweep_ev[8][2] = {};  // timing events of the dense sweeps, used in turn (sweep_device)
+    int sweep_ev_next = 0;
     hipStream_t copy_stream = nullptr;          // downloads that overlap the projection of the next chunk
     hipEvent_t chunk_ready[8] = {}, chunk_done[8] = {};
     bool have_sweep_time = false;
@@ -404,7 +408,15 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     DcsgLattice L = make_lattice(center, diam, res);
     const void* blob = c->d_blob.p;
     int nv = c->scene.blob_vec4();
-    if (time_it) HIPCHK(c, hipEventRecord(c->ev0, s));
+    // Timing events of the sweep: a ring of pairs, so that a new sweep never re-records an event whose previous record may
+    // still be in flight (back-to-back sweeps of a 0.1 ms kernel otherwise run in lock step with the host)
+    hipEvent_t t_ev0 = c->ev0, t_ev1 = c->ev1;
+    if (time_it) {
+        c->sweep_ev_next = (c->sweep_ev_next + 1) % 8;
+        t_ev0 = c->sweep_ev[c->sweep_ev_next][0];
+        t_ev1 = c->sweep_ev[c->sweep_ev_next][1];
+        HIPCHK(c, hipEventRecord(t_ev0, s));
+    }
     // launches cover whole planes, < 2^32 points each (the kernels' flat indices are 32-bit, byte offsets 64-bit): the
     // 1025^3 lattice is one launch (rounds 1-2: 2^30 points, i.e. 1022 planes and a 3-plane tail launch)
     const uint64_t plane = n1 * n1;
@@ -417,7 +429,8 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     // too large for them (or with rows shorter than a wave) takes the per-lane index path
     size_t lds = (c->scene.lds_bytes() + 15) & ~(size_t)15;
     int axes_off = -1;
-    if (n1 >= DCSG_WAVE && lds + 3 * n1 * sizeof(float) <= c->max_lds && c->variant != 4 && !getenv("DCSG_NO_AXIS_TABLES")) {
+    static const bool no_axis_tables = getenv("DCSG_NO_AXIS_TABLES") != nullptr;
+    if (n1 >= DCSG_WAVE && lds + 3 * n1 * sizeof(float) <= c->max_lds && c->variant != 4 && !no_axis_tables) {
         axes_off = (int)lds;
         lds += 3 * n1 * sizeof(float);
     }
@@ -426,24 +439,31 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     // coordinate (checked here with the kernels' arithmetic, dcsg_lattice_coord, in the same IEEE operations: this file
     // is built with -ffp-contract=off).
     unsigned flags = 0;
-    if (c->variant < 4 && d_sdf && axes_off >= 0 && !getenv("DCSG_NO_ROWS")) {
-        bool neg_zero = false;
-        for (int k = 0; k < 3 && !neg_zero; k++)
-            for (uint64_t i = 0; i < n1 && !neg_zero; i++) {
-                volatile float t = L.diam[k] * (float)(int)i;
-                volatile float u = L.w_pow2 ? t * L.inv_w : t / L.w;
-                volatile float v = L.base[k] + u;
-                float vv = v;
-                uint32_t b;
-                memcpy(&b, &vv, 4);
-                neg_zero = b == 0x80000000u;
-            }
-        if (!neg_zero) flags |= DCSG_SWEEP_ROWS;
+    static const bool no_rows = getenv("DCSG_NO_ROWS") != nullptr, no_multipass = getenv("DCSG_NO_MULTIPASS") != nullptr;
+    if (c->variant < 4 && d_sdf && axes_off >= 0 && !no_rows) {
+        // the answer depends on the lattice alone: remembered for the last one (a bench or a slab loop sweeps the same
+        // lattice again and again, and 3 (res+1) volatile float operations are microseconds of host time per launch)
+        if (!c->nz_valid || memcmp(&c->nz_lattice, &L, sizeof(L)) != 0) {
+            bool neg_zero = false;
+            for (int k = 0; k < 3 && !neg_zero; k++)
+                for (uint64_t i = 0; i < n1 && !neg_zero; i++) {
+                    volatile float t = L.diam[k] * (float)(int)i;
+                    volatile float u = L.w_pow2 ? t * L.inv_w : t / L.w;
+                    volatile float v = L.base[k] + u;
+                    float vv = v;
+                    uint32_t b;
+                    memcpy(&b, &vv, 4);
+                    neg_zero = b == 0x80000000u;
+                }
+            c->nz_lattice = L;
+            c->nz_result = neg_zero;
+            c->nz_valid = true;
+        }
+        if (!c->nz_result) flags |= DCSG_SWEEP_ROWS;
     }
-    if (!getenv("DCSG_NO_MULTIPASS")) flags |= DCSG_SWEEP_MULTIPASS;
+    if (!no_multipass) flags |= DCSG_SWEEP_MULTIPASS;
     {   // DCSG_SWEEP_FORM = run4 | merged (A/B builds with -DDCSG_SWEEP_FORMS only; the product has the plain form alone)
-        const char* form = getenv("DCSG_SWEEP_FORM");
-        const std::string f = form ? form : "plain";
+        static const std::string f = getenv("DCSG_SWEEP_FORM") ? getenv("DCSG_SWEEP_FORM") : "plain";
         if (f == "run4") flags |= DCSG_SWEEP_RUN4;
         else if (f == "merged") flags |= DCSG_SWEEP_MERGED;
     }
@@ -468,7 +488,7 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
         if (r) return r;
     }
     if (time_it) {
-        HIPCHK(c, hipEventRecord(c->ev1, s));
+        HIPCHK(c, hipEventRecord(t_ev1, s));
         c->have_sweep_time = true;
     }
     return 0;
@@ -521,6 +541,10 @@ int dcsg_create(dcsg_ctx** out, int device_id)
     lap.mark("hip_runtime_and_device");
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreate(&c->ev0));
+    for (auto& pr : c->sweep_ev) {
+        CK(hipEventCreate(&pr[0]));
+        CK(hipEventCreate(&pr[1]));
+    }
     CK(hipEventCreate(&c->ev1));
     CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int k = 0; k < 8; k++) {
@@ -581,6 +605,9 @@ void dcsg_destroy(dcsg_ctx* c)
     if (c->preview_mod) hipModuleUnload(c->preview_mod);
     if (c->builtin_mod) hipModuleUnload(c->builtin_mod);
     if (c->ev0) hipEventDestroy(c->ev0);
+    for (auto& pr : c->sweep_ev)
+        for (auto& e : pr)
+            if (e) hipEventDestroy(e);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (int k = 0; k < 8; k++) {
         if (c->chunk_ready[k]) hipEventDestroy(c->chunk_ready[k]);
@@ -602,6 +629,7 @@ int dcsg_render_preview(dcsg_ctx* c, const float campos[3], const float right[3]
     if (!campos || !right || !up || !forward || !rgb_out) return fail(c, DCSG_ERR_INVALID, "NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->preview_fn) {
+        join_rest_thread(c);  // one comgr action at a time per context: the background build of the rest part first
         std::string text = c->scene_cl_text.empty() ? std::string(builtin_scene_cl()) : c->scene_cl_text;
         std::string hsaco, log;
         Scene none;
@@ -859,9 +887,9 @@ int dcsg_last_sweep_ms(dcsg_ctx* c, double* ms)
     if (!c || !ms) return DCSG_ERR_INVALID;
     if (!c->have_sweep_time) return fail(c, DCSG_ERR_INVALID, "no sweep has been timed yet");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventSynchronize(c->sweep_ev[c->sweep_ev_next][1]));
     float t = 0;
-    HIPCHK(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
+    HIPCHK(c, hipEventElapsedTime(&t, c->sweep_ev[c->sweep_ev_next][0], c->sweep_ev[c->sweep_ev_next][1]));
     *ms = t;
     return 0;
 }

@@ -1296,6 +1296,8 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
 #else
     const bool merged = false;
 #endif
+    // (Tiles of T consecutive 1 024-point groups, to decouple the number of blocks from the number of write fronts, were
+    // measured and not kept: profiles/r03_ab/r03_ab_groups.txt.)
     for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const unsigned int local0 = tile * tile_points + wave * DCSG_RUN;  // wave-uniform from here ...
         if (local0 >= n_points) continue;
@@ -1316,11 +1318,18 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
         // kernel's registers go from 95 to 184 and the sweep from 1.04 to 1.45 ms -- measured, not kept.)
         if (K > 0 && MODE == 1 && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_MULTIPASS)) {
             float px[4], py[4], pz[4], o[4];
+            if (ix0 + DCSG_RUN <= n1) {  // the run lies inside one row (wave-uniform): one y, one z, no per-pass row tests
+                const float y = ax[n1 + iy0], z = ax[2u * n1 + plane0];
+                const float* xr = ax + ix0 + lane;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
-                px[j] = w.x, py[j] = w.y, pz[j] = w.z;
-                dcsg_wave_advance(n1, ix0, iy0, plane0);
+                for (int j = 0; j < 4; j++) px[j] = xr[64 * j], py[j] = y, pz[j] = z;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
+                    px[j] = w.x, py[j] = w.y, pz[j] = w.z;
+                    dcsg_wave_advance(n1, ix0, iy0, plane0);
+                }
             }
             dcsg_interp<(K <= 0 ? 4 : K), 4>(s, px, py, pz, o);
 #pragma unroll
