@@ -91,6 +91,7 @@ PROTOTYPES = {
     "dcsg_write_slab": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint]),
     "dcsg_load_profile": (C.c_char_p, [C.c_void_p, C.c_int]),
     "dcsg_last_sweep_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "dcsg_set_sweep_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "dcsg_compile_program": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                        C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "dcsg_expand_lookup_table": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]),

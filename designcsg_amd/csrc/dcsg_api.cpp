@@ -103,6 +103,7 @@ struct dcsg_ctx {
     hipStream_t copy_stream = nullptr;          // downloads that overlap the projection of the next chunk
     hipEvent_t chunk_ready[8] = {}, chunk_done[8] = {};
     bool have_sweep_time = false;
+    bool time_device_sweeps = false;  // dcsg_sweep_lattice_device records timing events (dcsg_set_sweep_timing)
     std::string err;
     std::string profile_create, profile_load;  // host-side timing breakdown of dcsg_create / the last dcsg_load_scene
 };
@@ -267,7 +268,14 @@ unsigned sweep_grid(const dcsg_ctx* c, unsigned tiles, unsigned tiles_per_block 
         unsigned want = tiles / tiles_per_block, hi = (unsigned)c->n_cu * 512u;
         cap = want < cap ? cap : (want > hi ? hi : want);
     }
-    return tiles < cap ? tiles : cap;
+    unsigned grid = tiles < cap ? tiles : cap;
+    // whole rounds of resident blocks (8 per CU): 131 841 tiles / 8 = 16 480 blocks would leave 96 blocks to a ninth,
+    // nearly empty round that ends a block's duration (a tenth of a 0.1 ms sweep) after everything else; rounded down, the
+    // grid-stride loop gives the first blocks one more tile instead
+    const unsigned slots = (unsigned)c->n_cu * 8u;
+    const bool whole_rounds = !getenv("DCSG_NO_WHOLE_ROUNDS");
+    if (whole_rounds && grid > slots) grid -= grid % slots;
+    return grid;
 }
 
 // How a scene's code object is obtained: the stand-alone module with the HIP-native brush bank, or a
@@ -429,7 +437,7 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     // too large for them (or with rows shorter than a wave) takes the per-lane index path
     size_t lds = (c->scene.lds_bytes() + 15) & ~(size_t)15;
     int axes_off = -1;
-    static const bool no_axis_tables = getenv("DCSG_NO_AXIS_TABLES") != nullptr;
+    const bool no_axis_tables = getenv("DCSG_NO_AXIS_TABLES") != nullptr;
     if (n1 >= DCSG_WAVE && lds + 3 * n1 * sizeof(float) <= c->max_lds && c->variant != 4 && !no_axis_tables) {
         axes_off = (int)lds;
         lds += 3 * n1 * sizeof(float);
@@ -439,7 +447,9 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     // coordinate (checked here with the kernels' arithmetic, dcsg_lattice_coord, in the same IEEE operations: this file
     // is built with -ffp-contract=off).
     unsigned flags = 0;
-    static const bool no_rows = getenv("DCSG_NO_ROWS") != nullptr, no_multipass = getenv("DCSG_NO_MULTIPASS") != nullptr;
+    // (diagnostic switches are read per call, not cached: tests flip them inside one process; four lookups are well under a
+    // microsecond of the five a launch costs the host)
+    const bool no_rows = getenv("DCSG_NO_ROWS") != nullptr, no_multipass = getenv("DCSG_NO_MULTIPASS") != nullptr;
     if (c->variant < 4 && d_sdf && axes_off >= 0 && !no_rows) {
         // the answer depends on the lattice alone: remembered for the last one (a bench or a slab loop sweeps the same
         // lattice again and again, and 3 (res+1) volatile float operations are microseconds of host time per launch)
@@ -463,7 +473,8 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     }
     if (!no_multipass) flags |= DCSG_SWEEP_MULTIPASS;
     {   // DCSG_SWEEP_FORM = run4 | merged (A/B builds with -DDCSG_SWEEP_FORMS only; the product has the plain form alone)
-        static const std::string f = getenv("DCSG_SWEEP_FORM") ? getenv("DCSG_SWEEP_FORM") : "plain";
+        const char* form = getenv("DCSG_SWEEP_FORM");
+        const std::string f = form ? form : "plain";
         if (f == "run4") flags |= DCSG_SWEEP_RUN4;
         else if (f == "merged") flags |= DCSG_SWEEP_MERGED;
     }
@@ -879,7 +890,16 @@ int dcsg_sweep_lattice_device(dcsg_ctx* c, const float center[3], const float di
                               float* d_sdf, float* d_normals, void* stream)
 {
     int r = need_scene(c);
-    return r ? r : sweep_device(c, center, diameters, res, z0, z1, d_sdf, d_normals, (hipStream_t)stream, true);
+    // timing events only on request (dcsg_set_sweep_timing): two event records per launch put several microseconds between
+    // back-to-back sweeps (513^3 SDF-only: 109 -> 10x us per launch over a region of launches)
+    return r ? r : sweep_device(c, center, diameters, res, z0, z1, d_sdf, d_normals, (hipStream_t)stream, c->time_device_sweeps);
+}
+
+int dcsg_set_sweep_timing(dcsg_ctx* c, int on)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    c->time_device_sweeps = on != 0;
+    return 0;
 }
 
 int dcsg_last_sweep_ms(dcsg_ctx* c, double* ms)

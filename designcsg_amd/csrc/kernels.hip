@@ -1123,15 +1123,25 @@ __device__ __forceinline__ unsigned int dcsg_div_n1(const DcsgLattice& L, unsign
 // Lattices with fewer than 64 points per row, or too large for the tables to fit in LDS (axes_off < 0), take the
 // per-lane path.
 // ---------------------------------------------------------------------------
+// XO ("x only"): the block fills the x table alone and y / z, which are wave-uniform per row, are computed where they are
+// needed (dcsg_axis) -- a third of the start-up work of a block, for the SDF-only sweep of per-scene code, whose 0.1 ms
+// launch pays that start-up eight times per CU.
+template <bool XO = false>
 __device__ __forceinline__ const float* dcsg_stage_axes(const DcsgLattice& L, int axes_off)
 {
     if (axes_off < 0 || L.res + 1 < DCSG_WAVE) return nullptr;
     float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(dcsg_lds) + axes_off);
     const int n1 = L.res + 1;
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < (XO ? 1 : 3); k++)
         for (int i = threadIdx.x; i < n1; i += DCSG_BLOCK) tab[k * n1 + i] = dcsg_lattice_coord(L, k, i);
     __syncthreads();
     return tab;
+}
+// coordinate i of axis 1 (y) or 2 (z): from the table, or computed (same arithmetic, same bits)
+template <bool XO>
+__device__ __forceinline__ float dcsg_axis(const DcsgLattice& L, const float* ax, int axis, unsigned int i)
+{
+    return XO ? dcsg_lattice_coord(L, axis, (int)i) : ax[(unsigned int)axis * ((unsigned int)L.res + 1u) + i];
 }
 
 // Position of this lane's point when the wave's first point is (ix0, iy0) of lattice plane plane0 (all wave-uniform).
@@ -1140,6 +1150,7 @@ struct DcsgWavePoint {
     float x, y, z;
     bool wrapped;  // lane is past the end of the wave's first row
 };
+template <bool XO = false>
 __device__ __forceinline__ DcsgWavePoint dcsg_wave_point(const DcsgLattice& L, const float* ax, unsigned int ix0, unsigned int iy0,
                                                          unsigned int plane0, unsigned int lane)
 {
@@ -1147,8 +1158,8 @@ __device__ __forceinline__ DcsgWavePoint dcsg_wave_point(const DcsgLattice& L, c
     DcsgWavePoint w;
     if (ix0 + (DCSG_WAVE - 1u) < n1) {  // wave-uniform: the whole wave lies in one row
         w.x = ax[ix0 + lane];
-        w.y = ax[n1 + iy0];
-        w.z = ax[2u * n1 + plane0];
+        w.y = dcsg_axis<XO>(L, ax, 1, iy0);
+        w.z = dcsg_axis<XO>(L, ax, 2, plane0);
         w.wrapped = false;
     } else {
         unsigned int iy1 = iy0 + 1u, plane1 = plane0;
@@ -1162,8 +1173,8 @@ __device__ __forceinline__ DcsgWavePoint dcsg_wave_point(const DcsgLattice& L, c
         w.wrapped = ix >= n1;
         ix = w.wrapped ? ix - n1 : ix;
         w.x = ax[ix];
-        w.y = ax[n1 + (w.wrapped ? iy1 : iy0)];
-        w.z = ax[2u * n1 + (w.wrapped ? plane1c : plane0)];
+        w.y = dcsg_axis<XO>(L, ax, 1, w.wrapped ? iy1 : iy0);
+        w.z = dcsg_axis<XO>(L, ax, 2, w.wrapped ? plane1c : plane0);
     }
     return w;
 }
@@ -1287,7 +1298,12 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
     // (positions from dcsg_lattice_coord per point, no LDS, no barrier, finer grids) was measured and not kept: 0.110 ms
     // at 513^3 and 0.82 against 0.75 ms at 1025^3 (profiles/r03_ab_notables.txt).
     SceneLds s = K < 0 ? SceneLds{} : dcsg_stage_scene(blob, n_vec4);
-    const float* ax = dcsg_stage_axes(L, axes_off);
+#ifdef DCSG_NO_XONLY  // A/B builds
+    constexpr bool XO = false;
+#else
+    constexpr bool XO = K < 0 && MODE == 1;  // SDF-only sweep of per-scene code: x table only (dcsg_stage_axes)
+#endif
+    const float* ax = dcsg_stage_axes<XO>(L, axes_off);
     const bool want_sdf = MODE == 0 ? sdf_out != nullptr : true;
     const bool want_nrm = MODE == 0 ? nrm_out != nullptr : MODE == 3;
 #if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
@@ -1319,14 +1335,14 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
         if (K > 0 && MODE == 1 && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_MULTIPASS)) {
             float px[4], py[4], pz[4], o[4];
             if (ix0 + DCSG_RUN <= n1) {  // the run lies inside one row (wave-uniform): one y, one z, no per-pass row tests
-                const float y = ax[n1 + iy0], z = ax[2u * n1 + plane0];
+                const float y = dcsg_axis<XO>(L, ax, 1, iy0), z = dcsg_axis<XO>(L, ax, 2, plane0);
                 const float* xr = ax + ix0 + lane;
 #pragma unroll
                 for (int j = 0; j < 4; j++) px[j] = xr[64 * j], py[j] = y, pz[j] = z;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
+                    DcsgWavePoint w = dcsg_wave_point<XO>(L, ax, ix0, iy0, plane0, lane);
                     px[j] = w.x, py[j] = w.y, pz[j] = w.z;
                     dcsg_wave_advance(n1, ix0, iy0, plane0);
                 }
@@ -1350,13 +1366,13 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                 const float* xr = ax + ix0 + lane;
 #pragma unroll
                 for (int j = 0; j < 4; j++) x4[j] = xr[64 * j];
-                const float y = ax[n1 + iy0], z = ax[2u * n1 + plane0];
+                const float y = dcsg_axis<XO>(L, ax, 1, iy0), z = dcsg_axis<XO>(L, ax, 2, plane0);
                 y4 = y;
                 z4 = z;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
+                    DcsgWavePoint w = dcsg_wave_point<XO>(L, ax, ix0, iy0, plane0, lane);
                     x4[j] = w.x, y4[j] = w.y, z4[j] = w.z;
                     dcsg_wave_advance(n1, ix0, iy0, plane0);
                 }
@@ -1387,7 +1403,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
         if (K < 0 && MODE == 1 && ax && left >= DCSG_RUN && ix0 + DCSG_RUN <= n1 && dcsg_spec_small()) {
             // SDF only: a whole run inside one row (half of the runs at 513 points per row, three quarters at 1025), its
             // four x reads issued together, four passes unrolled
-            const float y = ax[n1 + iy0], z = ax[2u * n1 + plane0];
+            const float y = dcsg_axis<XO>(L, ax, 1, iy0), z = dcsg_axis<XO>(L, ax, 2, plane0);
             const float* xrow = ax + ix0 + lane;
 #pragma unroll
             for (unsigned int k = 0u; k < DCSG_RUN / DCSG_WAVE; k++) row_pass(xrow, y, z, k);
@@ -1397,7 +1413,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
         auto pass = [&](unsigned int done) {
             float x, y, z;
             if (ax) {
-                DcsgWavePoint w = dcsg_wave_point(L, ax, ix0, iy0, plane0, lane);
+                DcsgWavePoint w = dcsg_wave_point<XO>(L, ax, ix0, iy0, plane0, lane);
                 x = w.x, y = w.y, z = w.z;
                 dcsg_wave_advance(n1, ix0, iy0, plane0);
             } else {
@@ -1450,7 +1466,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                     k++;
                     continue;
                 }
-                const float y = ax[n1 + iy0], z = ax[2u * n1 + plane0];
+                const float y = dcsg_axis<XO>(L, ax, 1, iy0), z = dcsg_axis<XO>(L, ax, 2, plane0);
                 const float* xrow = ax + ix0 + lane;
 #pragma unroll 1
                 for (unsigned int q = 0u; q < m; q++) row_pass(xrow, y, z, q);
@@ -1484,8 +1500,11 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
 // SDF-only kernels of per-scene code (K < 0, MODE 1): at least 8 waves per SIMD, i.e. at most 64 VGPRs -- the allocator
 // otherwise lets the four unrolled passes drift to 65, one wave per SIMD less (sphere: 23 under the bound, Design2: 47,
 // no spill).  Not for SDF + normals: Design2's seven stencil evaluations of a 63-box brush spill under it.
+#ifndef DCSG_SWEEP_MIN_WAVES
+#define DCSG_SWEEP_MIN_WAVES 1  // A/B builds: minimum waves per SIMD asked of the other sweep kernels
+#endif
 #define DCSG_SWEEP_KERNEL(NAME, K, MODE)                                                                            \
-    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, ((K) < 0 && (MODE) == 1 ? 8 : 1))                      \
+    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, ((K) < 0 && (MODE) == 1 ? 8 : DCSG_SWEEP_MIN_WAVES))   \
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first,                     \
          unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_out, int axes_off,             \
          unsigned int flags)                                                                                        \

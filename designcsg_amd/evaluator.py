@@ -138,6 +138,10 @@ class Evaluator:
                                                    C.c_void_p(d_sdf or None), C.c_void_p(d_normals or None),
                                                    C.c_void_p(stream or None)))
 
+    def set_sweep_timing(self, on=True):
+        """Timing events around the sweeps of sweep_lattice_device (off by default; last_sweep_ms needs them)."""
+        self._ck(self._L.dcsg_set_sweep_timing(self._h, 1 if on else 0))
+
     def last_sweep_ms(self):
         ms = C.c_double()
         self._ck(self._L.dcsg_last_sweep_ms(self._h, C.byref(ms)))

@@ -233,8 +233,12 @@ int dcsg_export_multi(dcsg_ctx* const* ctxs, int n, const char* export_config_tx
  * 1: its last dcsg_load_scene.  The string lives until the next load / destroy. */
 const char* dcsg_load_profile(const dcsg_ctx* ctx, int which);
 
-/* Device time in ms of the most recent lattice sweep (HIP events on its stream; synchronises). */
+/* Device time in ms of the most recent TIMED lattice sweep (HIP events on its stream; synchronises): the sweeps of
+ * dcsg_eval_lattice and of the exports always are; those of dcsg_sweep_lattice_device only after
+ * dcsg_set_sweep_timing(ctx, 1) -- the two event records put several microseconds between back-to-back launches, which an
+ * asynchronous caller should not pay by default. */
 int dcsg_last_sweep_ms(dcsg_ctx* ctx, double* ms);
+int dcsg_set_sweep_timing(dcsg_ctx* ctx, int on);
 
 /* ---- host-only diagnostics (no device needed; used by the CPU test-suite) ---------------------- */
 /* What dcsg_load_scene makes of a build procedure: the register program after fusion and slot renaming

@@ -305,6 +305,33 @@ def test_lattice_sweep_bit_exact(ev, oracle, name):
         assert np.array_equal(bits(gs6), bits(osc.eval_lattice(center, diameter[0], r, normals=False)[0]))
 
 
+@pytest.mark.parametrize("name", ["sphere", "mixed_groups", "design2", "smooth_blobs"])
+@pytest.mark.parametrize("env", [{"DCSG_SPECIALISE": "0"}, {"DCSG_SPECIALISE": "0", "DCSG_NO_MULTIPASS": "1"},
+                                 {"DCSG_SPECIALISE": "0", "DCSG_CULL": "0", "DCSG_FORCE_VARIANT": "0"}],
+                         ids=["stack", "stack_single_pass", "generic"])
+def test_interpreter_lattice_sweeps_bit_exact(ev, oracle, name, env, monkeypatch):
+    """Dense sweeps through the LDS-table interpreters (what every scene the specialiser refuses runs): rows of at least
+    64 points use the axis tables, and the SDF-only sweep of the stack interpreters carries a lane's point of each of a
+    run's four passes through ONE interpretation of the program (dcsg_interp<K, 4>).  Whole lattices at 97 and 257
+    points per row against the oracle, SDF + normals, SDF only, a Z slab, a box that is not centred."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    load(ev, name)
+    assert ev.scene_info()["interpreter"] in ((0,) if "DCSG_FORCE_VARIANT" in env else (1, 2)), ev.scene_info()
+    osc = oracle.Scene.from_dir(scene_dir(name))
+    center, diameter, _ = osc.estimate_bounding_box(10.0)
+    for c, d, res in ((center, diameter[0], 96), ([center[0] + 0.0131, center[1] - 0.0077, center[2] + 0.0253], diameter[0] * 1.037, 256)):
+        if res == 256 and name == "design2" and "DCSG_FORCE_VARIANT" in env:
+            continue          # the generic interpreter on a 63-box brush: keep the oracle's and the GPU's share short
+        ws, wn = osc.eval_lattice(c, d, res)
+        gs, gn = ev.eval_lattice(c, d, res)
+        assert np.array_equal(bits(gs), bits(ws)) and np.array_equal(bits(gn), bits(wn))
+        gs2, _ = ev.eval_lattice(c, d, res, normals=False)
+        assert np.array_equal(bits(gs2), bits(ws))
+        gs3, _ = ev.eval_lattice(c, d, res, z0=res // 3, z1=res // 3 + 9, normals=False)
+        assert np.array_equal(bits(gs3), bits(ws[res // 3:res // 3 + 9]))
+
+
 LIGHT_DESIGNS = {
     # standard brushes only, at most four object evaluations: what the row kernels (dcsg_sweep_rows) are generated for
     "sphere_offset": "draw(sphere_brush, Transform.initial(np.array([0.31, -0.17, 0.08]), 0.4, -0.7, 1.1, np.array([0.9, 0.6, 0.75])))",
