@@ -82,7 +82,6 @@ struct dcsg_ctx {
     Kernels* k = nullptr;  // active
     bool scene_loaded = false, jit = false, specialised = false;
     bool light_scene = false;  // at most four evaluations of standard brushes: its sweeps are store-bound (sweep_grid)
-    bool row_kernels = false;  // the scene module holds dcsg_spec_row4*: dense sweeps may take dcsg_sweep_rows
     DcsgLattice nz_lattice;    // sweep_device: the lattice last checked for a -0.0 coordinate, and the answer
     bool nz_valid = false, nz_result = false;
     int numerics = 0;  // DCSG_NUMERICS_EXACT / _RELAXED for the scenes loaded from now on (dcsg_set_numerics)
@@ -282,7 +281,6 @@ unsigned sweep_grid(const dcsg_ctx* c, unsigned tiles, unsigned tiles_per_block 
 // module compiled from its scene.cl (+ the generated specialisation of its build procedure).
 struct ModulePlan {
     bool needs_jit = false, specialise = false, null0 = true, relaxed = false, light = false;
-    bool rows = false;  // the module holds the row kernels' evaluation (dense sweeps of store-bound scenes)
     std::string cl, extra;
 };
 
@@ -315,7 +313,7 @@ bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std:
     if (p.needs_jit) {
         if (builtin_only) p.cl = builtin_scene_cl();
         p.null0 = builtin_only || scene_cl_null_brush_is_const(p.cl);
-        p.extra = specialised_source(s, p.null0, p.specialise, builtin_only && !getenv("DCSG_NO_SIMPLIFY"), &p.rows);
+        p.extra = specialised_source(s, p.null0, p.specialise, builtin_only && !getenv("DCSG_NO_SIMPLIFY"));
     }
     return true;
 }
@@ -469,7 +467,7 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
             c->nz_result = neg_zero;
             c->nz_valid = true;
         }
-        if (!c->nz_result) flags |= DCSG_SWEEP_ROWS;
+        if (!c->nz_result) flags |= DCSG_SWEEP_NO_NEG_ZERO;
     }
     if (!no_multipass) flags |= DCSG_SWEEP_MULTIPASS;
     {   // DCSG_SWEEP_FORM = run4 | merged (A/B builds with -DDCSG_SWEEP_FORMS only; the product has the plain form alone)
@@ -774,7 +772,6 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     }
     c->specialised = c->jit && plan.specialise;
     c->light_scene = plan.light;
-    c->row_kernels = c->jit && plan.specialise && plan.rows;
     c->scene_relaxed = plan.relaxed;
     // every kernel stages the scene tables in LDS: they must fit one workgroup's share (160 KiB on gfx950)
     if (s.lds_bytes() > c->max_lds)

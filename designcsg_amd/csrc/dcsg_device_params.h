@@ -8,7 +8,7 @@
 #define DCSG_MAX_SLOTS 64  /* STACK_MEMORY_PER_PIXEL, Evaluator.cpp:7 */
 /* dcsg_sweep* `flags`: bit 0 = the lattice holds no -0.0 coordinate (checked by the host), so the sweep may evaluate
  * four points per lane with shared unperturbed coordinates (kernels.hip, dcsg_run4) */
-#define DCSG_SWEEP_ROWS 1u
+#define DCSG_SWEEP_NO_NEG_ZERO 1u
 /* bit 1 = the stack interpreters may serve several 64-point passes with one interpretation of the program */
 #define DCSG_SWEEP_MULTIPASS 2u
 /* bits 2, 3: which form the dense sweep of a store-bound scene takes (standard brushes, <= 4 object evaluations): four

@@ -1058,7 +1058,7 @@ __device__ __forceinline__ void dcsg_stencil_spec(float x, float y, float z, boo
 // MEASURED AND NOT KEPT (round 3; DCSG_SWEEP_FORM=merged in a -DDCSG_SWEEP_FORMS build): 136 instead of 146 VALU
 // instructions per lattice point, 60 % instead of 76 % VALU utilisation, 6 % slower.
 // dcsg_stencil_spec<true> (SDF + normal) for scenes of standard brushes on a lattice without a -0.0 coordinate (the host's
-// DCSG_SWEEP_ROWS check): the seven square roots of the brushes and the normalisation run in one basic block, their
+// DCSG_SWEEP_NO_NEG_ZERO check): the seven square roots of the brushes and the normalisation run in one basic block, their
 // operand tests merged into one ballot per point (dcsg_spec_eval7a, dcsg_finish_normal_acc) instead of eight
 // compare-and-branch pairs; a wave that fails the test recomputes through the guarded code.  Same bits.
 __device__ __forceinline__ void dcsg_stencil_spec_merged(float x, float y, float z, float& sdf, float& nx, float& ny, float& nz)
@@ -1220,7 +1220,7 @@ __device__ __forceinline__ void dcsg_wave_advance(unsigned int n1, unsigned int&
 // 4-byte offset, every instruction leaves two partial 128-byte lines to another wave, and the sweep takes 1.5-2x as
 // long; a lane owning four CONSECUTIVE points with 16-byte stores at a 48-byte stride for the normals: 0.70 of the
 // HBM peak as plain stores and 0.27 as non-temporal ones, against 0.80 for the pattern kept here.
-// The host sets DCSG_SWEEP_ROWS only for lattices without a -0.0 coordinate (the stencil's "+ 0.0f" would change it:
+// The host sets DCSG_SWEEP_NO_NEG_ZERO only for lattices without a -0.0 coordinate (the stencil's "+ 0.0f" would change it:
 // dcsg_stencil_spec).
 // ---------------------------------------------------------------------------
 // x, y, z: the lane's four points (pass j of the run); in_row: y and z are the same for all four (wave-uniform)
@@ -1308,7 +1308,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
     const bool want_nrm = MODE == 0 ? nrm_out != nullptr : MODE == 3;
 #if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
     // one merged guard per lattice point (dcsg_stencil_spec_merged): standard brushes, no -0.0 coordinate on the lattice
-    const bool merged = K < 0 && (flags & DCSG_SWEEP_ROWS) && (flags & DCSG_SWEEP_MERGED) && dcsg_spec_row4_ok();
+    const bool merged = K < 0 && (flags & DCSG_SWEEP_NO_NEG_ZERO) && (flags & DCSG_SWEEP_MERGED) && dcsg_spec_row4_ok();
 #else
     const bool merged = false;
 #endif
@@ -1353,7 +1353,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             continue;
         }
 #if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
-        if (K < 0 && (MODE == 1 || MODE == 3) && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_ROWS) && (flags & DCSG_SWEEP_RUN4) &&
+        if (K < 0 && (MODE == 1 || MODE == 3) && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_NO_NEG_ZERO) && (flags & DCSG_SWEEP_RUN4) &&
             dcsg_spec_row4_ok()) {
             // four points per lane (dcsg_run4): the lane's share of each of the run's four passes
             dcsg_cl_float4 x4, y4, z4;

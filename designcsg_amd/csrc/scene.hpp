@@ -63,8 +63,7 @@ float angle_threshold_to_q_star(float threshold);
 
 // csrc/specialise.cpp
 // simplify: the scene uses only the five standard brushes (see specialise.cpp for what that licenses)
-// rows_out: set when the text holds the row kernels' evaluation (dcsg_spec_row4*, kernels.hip: dcsg_sweep_rows)
-std::string specialised_source(const Scene& s, bool null_brush_const, bool enable, bool simplify, bool* rows_out = nullptr);
+std::string specialised_source(const Scene& s, bool null_brush_const, bool enable, bool simplify);
 const char* builtin_scene_cl();
 
 uint64_t fnv1a64(const void* data, size_t n, uint64_t seed);

@@ -42,7 +42,7 @@ float dcsg_sqrt_ieee(float x){
     return r;
 }
 #endif
-/* Row kernels of standard-brush scenes (csrc/specialise.cpp, layouts 1 and 2): the same fast sequence WITHOUT its own
+/* Deferred-guard forms of standard-brush scenes (csrc/specialise.cpp, layouts 1-5; A/B builds only): the same fast sequence WITHOUT its own
  * branch; the range test on the first estimate g (an ordinary input <=> 0x27800000 <= bits(g) < 0x7f800000, see
  * dcsg_sqrt in kernels.hip) is folded into a running unsigned minimum and maximum of bits(g) -- one v_min3_u32 /
  * v_max3_u32 per two square roots -- which the kernel tests once per four lattice points; a wave that fails the test

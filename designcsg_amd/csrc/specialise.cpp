@@ -23,10 +23,10 @@ static std::string hexf(float f)
 }
 
 // layout: 0 = N stencil points passed as float8 lanes (N = 7) or one point (N = 1);
-//         1 = row kernel, SDF + normals: 4 consecutive lattice points x (float4), shared y and z, 7 stencil points each
+//         1 = four lattice points per lane (kernels.hip: dcsg_run4), SDF + normals: their x (float4), shared y and z, 7 stencil points each
 //             (N = 28, point 7 j + k = lattice point j, stencil point k), standard brushes written inline with the
 //             deferred square-root guard (scene_prelude.cl: dcsg_std_brush_acc);
-//         2 = row kernel, SDF only: the 4 lattice points (N = 4);
+//         2 = the same, SDF only: the 4 lattice points (N = 4);
 //         3, 4 = as 1, 2 with every lattice point's own y and z (float4): a run that crosses a row end;
 //         5 = the N = 7 stencil points of ONE lattice point (float8 lanes, as layout 0) with the standard brushes inline
 //             and the deferred square-root guard: returns float16 (o0..o6, 0, bits of gmn, bits of gmx, 0...).
@@ -217,9 +217,8 @@ static const char kRow4Stubs[] =
 // OpenCL C for dcsg_spec_eval7 / dcsg_spec_eval1.  With `enable` false (or a program that is not
 // stack-disciplined) it emits stubs, which only satisfy the linker: the host never selects the
 // specialised kernels for such a scene.
-std::string specialised_source(const Scene& s, bool null_brush_const, bool enable, bool simplify, bool* rows_out)
+std::string specialised_source(const Scene& s, bool null_brush_const, bool enable, bool simplify)
 {
-    if (rows_out) *rows_out = false;
     std::string out = "\n/* ---- generated by csrc/specialise.cpp ---- */\n";
     if (!enable || s.n_stack_prog == 0) {
         out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){ return (float8)(0.0f); }\n";
@@ -240,7 +239,7 @@ std::string specialised_source(const Scene& s, bool null_brush_const, bool enabl
         if (((op >= 32 && op <= 35) || (op >= 41 && op <= 43)) && !(brush == 0 && null_brush_const)) evals++;
     }
     out += std::string("__attribute__((always_inline)) int dcsg_spec_small(void){ return ") + (evals <= 4 ? "1" : "0") + "; }\n";
-    // Row kernels (kernels.hip, dcsg_sweep_rows): a lane owns four consecutive lattice points of one row.  Only for
+    // Four points per lane / one merged guard per point (kernels.hip: dcsg_run4, dcsg_stencil_spec_merged).  Only for
     // scenes of standard brushes (`simplify`: their bodies are written inline, so that the square roots' range tests can
     // be merged) with at most four object evaluations (the dense sweeps of such a scene are store-bound).
     // (round 3: measured and not kept -- fewer instructions, lower VALU utilisation, more time; the evaluation is generated
@@ -252,7 +251,6 @@ std::string specialised_source(const Scene& s, bool null_brush_const, bool enabl
         emit_function(s, null_brush_const, 4, simplify, "", out, 4);
         emit_function(s, null_brush_const, 7, simplify, "", out, 5);
         out += "__attribute__((always_inline)) int dcsg_spec_row4_ok(void){ return 1; }\n";
-        if (rows_out) *rows_out = true;
     } else {
         out += kRow4Stubs;
     }
