@@ -448,7 +448,7 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     // (diagnostic switches are read per call, not cached: tests flip them inside one process; four lookups are well under a
     // microsecond of the five a launch costs the host)
     const bool no_rows = getenv("DCSG_NO_ROWS") != nullptr, no_multipass = getenv("DCSG_NO_MULTIPASS") != nullptr;
-    if (c->variant < 4 && d_sdf && axes_off >= 0 && !no_rows) {
+    if (c->variant < 4 && d_sdf && axes_off >= 0 && !no_rows && getenv("DCSG_SWEEP_FORM")) {  // only the A/B forms ask
         // the answer depends on the lattice alone: remembered for the last one (a bench or a slab loop sweeps the same
         // lattice again and again, and 3 (res+1) volatile float operations are microseconds of host time per launch)
         if (!c->nz_valid || memcmp(&c->nz_lattice, &L, sizeof(L)) != 0) {

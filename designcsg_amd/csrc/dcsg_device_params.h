@@ -6,8 +6,8 @@
 #define DCSG_BLOCK 256
 #define DCSG_WAVE 64
 #define DCSG_MAX_SLOTS 64  /* STACK_MEMORY_PER_PIXEL, Evaluator.cpp:7 */
-/* dcsg_sweep* `flags`: bit 0 = the lattice holds no -0.0 coordinate (checked by the host), so the sweep may evaluate
- * four points per lane with shared unperturbed coordinates (kernels.hip, dcsg_run4) */
+/* dcsg_sweep* `flags`: bit 0 = the lattice holds no -0.0 coordinate (checked by the host), so a sweep may share the
+ * unperturbed stencil coordinates between points without looking (A/B forms of kernels.hip: dcsg_run4, dcsg_stencil_spec_merged) */
 #define DCSG_SWEEP_NO_NEG_ZERO 1u
 /* bit 1 = the stack interpreters may serve several 64-point passes with one interpretation of the program */
 #define DCSG_SWEEP_MULTIPASS 2u

@@ -277,11 +277,11 @@ def test_lattice_sweep_bit_exact(ev, oracle, name):
     res = 48  # not a power of two: exercises the x/w division path
     if name in ("flat256", "grouped256", "smooth256"):  # hundreds of objects: keep the oracle's share short; culling kernels on the GPU
         assert ev.scene_info()["interpreter"] == 4
-        for r in (24, 32):
+        for r in (24, 32, 75):   # 76 points per row: bricks clipped at the far faces, quarters of a brick left empty
             gs, gn = ev.eval_lattice(center, diameter[0], r)
             ws, wn = osc.eval_lattice(center, diameter[0], r)
             assert np.array_equal(bits(gs), bits(ws)) and np.array_equal(bits(gn), bits(wn))
-        gs2, _ = ev.eval_lattice(center, diameter[0], 32, normals=False)  # SDF-only path of the same kernel
+        gs2, _ = ev.eval_lattice(center, diameter[0], 75, normals=False)  # SDF-only form of the same kernel
         assert np.array_equal(bits(gs2), bits(ws))
         return
     for r in (res, 64):
@@ -306,7 +306,7 @@ def test_lattice_sweep_bit_exact(ev, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["sphere", "mixed_groups", "design2", "smooth_blobs"])
-@pytest.mark.parametrize("env", [{"DCSG_SPECIALISE": "0"}, {"DCSG_SPECIALISE": "0", "DCSG_NO_MULTIPASS": "1"},
+@pytest.mark.parametrize("env", [{"DCSG_SPECIALISE": "0", "DCSG_CULL": "0"}, {"DCSG_SPECIALISE": "0", "DCSG_CULL": "0", "DCSG_NO_MULTIPASS": "1"},
                                  {"DCSG_SPECIALISE": "0", "DCSG_CULL": "0", "DCSG_FORCE_VARIANT": "0"}],
                          ids=["stack", "stack_single_pass", "generic"])
 def test_interpreter_lattice_sweeps_bit_exact(ev, oracle, name, env, monkeypatch):
