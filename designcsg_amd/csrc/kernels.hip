@@ -1198,6 +1198,53 @@ __device__ __forceinline__ void dcsg_wave_advance(unsigned int n1, unsigned int&
 #else
 #define DCSG_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #endif
+// The sweeps' stores as "scalar base + 32-bit lane offset" (global_store ... s[base:base+1]): a wave's base is uniform (SGPRs,
+// advanced by scalar adds), so a pass spends no vector instruction on addresses -- left to itself the compiler keeps
+// "pointer + lane" in a VGPR pair and pays two 64-bit vector adds per pass (a v_mad_u64_u32 in the general path).  Sphere
+// fused 513^3 0.458 -> 0.450 ms, 1025^3 3.54 -> 3.47 (profiles/r03_ab/r03_ab_stores2.txt, r03_ab_saddr.txt).  Used by the
+// SDF + normal sweep of per-scene code only: the SDF-only sweep (+3-4 %) and the interpreters (+1 %) were slower with it.
+// `base` MUST be wave-uniform.
+// No "memory" clobber: no sweep reads the lattice back, and the clobber would order the passes' LDS reads behind the stores.
+#ifdef DCSG_NO_SADDR_STORES  // A/B builds
+__device__ __forceinline__ void dcsg_store_lane(float* base, unsigned int lane, float v) { DCSG_STREAM_STORE(v, base + lane); }
+__device__ __forceinline__ void dcsg_store3_lane(float* base, unsigned int lane, float a, float b, float c)
+{
+    DCSG_STREAM_STORE(a, base + lane * 3u);
+    DCSG_STREAM_STORE(b, base + lane * 3u + 1);
+    DCSG_STREAM_STORE(c, base + lane * 3u + 2);
+}
+#else
+typedef float dcsg_store_f3 __attribute__((ext_vector_type(3)));
+// SGPR copy of a wave-uniform pointer (folds away where the compiler already knows the value to be uniform)
+__device__ __forceinline__ float* dcsg_uniform_ptr(float* p)
+{
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)u);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(u >> 32));
+    return (float*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void dcsg_store_lane(float* base, unsigned int lane, float v)
+{
+    base = dcsg_uniform_ptr(base);
+    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(lane * 4u), "v"(v), "s"(base));
+}
+__device__ __forceinline__ void dcsg_store3_lane(float* base, unsigned int lane, float a, float b, float c)
+{
+    base = dcsg_uniform_ptr(base);
+    dcsg_store_f3 n3 = {a, b, c};
+    // the s_nop is the wait state a VALU write of the data registers of a > 8-byte store needs (the compiler's hazard
+    // recogniser does not look inside asm)
+    asm volatile("global_store_dwordx3 %0, %1, %2 nt\n\ts_nop 0" ::"v"(lane * 12u), "v"(n3), "s"(base));
+}
+#endif
+// A/B builds only (timing, wrong output): -DDCSG_EXPERIMENT_NOSTORE runs the sweeps' arithmetic WITHOUT their store stream --
+// the stores sit behind a test of the computed values that no lattice point passes, so nothing is sunk or dropped
+// (profiles/r03_ab/r03_ab_nostore.txt: what the store stream costs the fused sweep).
+#ifdef DCSG_EXPERIMENT_NOSTORE
+#define DCSG_STORE_GATE(a, b, c, d) if (__builtin_amdgcn_ballot_w64((a) + (b) + (c) + (d) == 1.0e30f) != 0ull)
+#else
+#define DCSG_STORE_GATE(a, b, c, d)
+#endif
 
 #if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
 // ---------------------------------------------------------------------------
@@ -1257,7 +1304,7 @@ __device__ __forceinline__ void dcsg_run4(const dcsg_cl_float4& x, const dcsg_cl
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 4; j++) DCSG_STORE_GATE(sd[j], nx[j], ny[j], nz[j]) {
             DCSG_STREAM_STORE(sd[j], sdf_at + 64 * j);
             DCSG_STREAM_STORE(nx[j], nrm_at + 192 * j);
             DCSG_STREAM_STORE(ny[j], nrm_at + 192 * j + 1);
@@ -1387,17 +1434,22 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
         // operations, same bits), and the per-pass row tests disappear.
         auto row_pass = [&](const float* xrow, float y, float z, unsigned int k) {
             float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+#ifdef DCSG_EXPERIMENT_NOCOMPUTE  // A/B builds only (timing, wrong output): the sweep's store stream without its arithmetic
+            sd = nz = xrow[k * DCSG_WAVE], nx = y, ny = z;
+#else
 #ifdef DCSG_SWEEP_FORMS
             if (MODE == 3 && merged) dcsg_stencil_spec_merged(xrow[k * DCSG_WAVE], y, z, sd, nx, ny, nz);
             else
 #endif
                 dcsg_stencil_spec<true>(xrow[k * DCSG_WAVE], y, z, true, MODE == 3, sd, nx, ny, nz);
-            __builtin_nontemporal_store(sd, (sdf_out + idx0) + lane + k * DCSG_WAVE);
-            if (MODE == 3) {
-                float* o = nrm_out + (size_t)idx0 * 3 + (lane + k * DCSG_WAVE) * 3u;
-                __builtin_nontemporal_store(nx, o);
-                __builtin_nontemporal_store(ny, o + 1);
-                __builtin_nontemporal_store(nz, o + 2);
+#endif
+            DCSG_STORE_GATE(sd, nx, ny, nz) {
+                if (MODE == 3) {
+                    dcsg_store_lane(sdf_out + idx0 + k * DCSG_WAVE, lane, sd);
+                    dcsg_store3_lane(nrm_out + ((size_t)idx0 + k * DCSG_WAVE) * 3, lane, nx, ny, nz);
+                } else {
+                    DCSG_STREAM_STORE(sd, (sdf_out + idx0) + lane + k * DCSG_WAVE);
+                }
             }
         };
         if (K < 0 && MODE == 1 && ax && left >= DCSG_RUN && ix0 + DCSG_RUN <= n1 && dcsg_spec_small()) {
@@ -1426,6 +1478,8 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                 y = dcsg_lattice_coord(L, 1, (int)iy);
                 z = dcsg_lattice_coord(L, 2, (int)iz + z0);
             }
+            const unsigned int at = idx0;  // this pass's first point; advanced here, ahead of the divergent return, so that
+            idx0 += DCSG_WAVE;             // idx0 stays a wave-uniform value for the compiler
             if (left - done < DCSG_WAVE && lane >= left - done) return;  // the launch's last wave
             float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
             if (K == 0) {
@@ -1433,25 +1487,35 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                 if (want_nrm) dcsg_get_normal(s, x, y, z, nx, ny, nz);
 #ifdef DCSG_HAVE_SPEC
             } else if (K < 0) {
+#ifdef DCSG_EXPERIMENT_NOCOMPUTE
+                sd = nz = x, nx = y, ny = z;
+#else
 #ifdef DCSG_SWEEP_FORMS
                 if (MODE == 3 && merged) dcsg_stencil_spec_merged(x, y, z, sd, nx, ny, nz);
                 else
 #endif
                     dcsg_stencil_spec<true>(x, y, z, want_sdf, want_nrm, sd, nx, ny, nz);
 #endif
+#endif
             } else {
                 dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, want_sdf, want_nrm, sd, nx, ny, nz);
             }
-            // wave-uniform base + lane: the store addresses cost no per-lane multiplies
             // write-once streaming output: non-temporal stores (nothing in this kernel reads the lattice back)
-            if (want_sdf) __builtin_nontemporal_store(sd, (sdf_out + idx0) + lane);
-            if (want_nrm) {
-                float* o = nrm_out + (size_t)idx0 * 3 + lane * 3u;
-                __builtin_nontemporal_store(nx, o);
-                __builtin_nontemporal_store(ny, o + 1);
-                __builtin_nontemporal_store(nz, o + 2);
+            DCSG_STORE_GATE(sd, nx, ny, nz) {
+                if (K < 0 && MODE == 3) {
+                    dcsg_store_lane(sdf_out + at, lane, sd);
+                    dcsg_store3_lane(nrm_out + (size_t)at * 3, lane, nx, ny, nz);
+                } else {
+                    // wave-uniform base + lane: the store addresses cost no per-lane multiplies
+                    if (want_sdf) DCSG_STREAM_STORE(sd, (sdf_out + at) + lane);
+                    if (want_nrm) {
+                        float* o = nrm_out + (size_t)at * 3 + lane * 3u;
+                        DCSG_STREAM_STORE(nx, o);
+                        DCSG_STREAM_STORE(ny, o + 1);
+                        DCSG_STREAM_STORE(nz, o + 2);
+                    }
+                }
             }
-            idx0 += DCSG_WAVE;
         };
 #ifdef DCSG_HAVE_SPEC
         if (K < 0 && MODE == 3 && ax && left >= DCSG_RUN && dcsg_spec_small()) {
