@@ -440,15 +440,15 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
         axes_off = (int)lds;
         lds += 3 * n1 * sizeof(float);
     }
-    // Several points per lane with shared unperturbed stencil coordinates (kernels.hip: dcsg_run4 for store-bound scenes,
-    // the multi-pass interpretation of the stack interpreters): needs the axis tables and a lattice without a -0.0
-    // coordinate (checked here with the kernels' arithmetic, dcsg_lattice_coord, in the same IEEE operations: this file
-    // is built with -ffp-contract=off).
+    // DCSG_SWEEP_NO_NEG_ZERO: no coordinate of this lattice is -0.0 (checked here with the kernels' arithmetic,
+    // dcsg_lattice_coord, in the same IEEE operations: this file is built with -ffp-contract=off), so the normal stencil's
+    // "+ 0.0f" changes nothing and the sweeps of per-scene code skip their per-pass test for it.
     unsigned flags = 0;
     // (diagnostic switches are read per call, not cached: tests flip them inside one process; four lookups are well under a
     // microsecond of the five a launch costs the host)
     const bool no_rows = getenv("DCSG_NO_ROWS") != nullptr, no_multipass = getenv("DCSG_NO_MULTIPASS") != nullptr;
-    if (c->variant < 4 && d_sdf && axes_off >= 0 && !no_rows && getenv("DCSG_SWEEP_FORM")) {  // only the A/B forms ask
+    // read by the SDF + normal sweeps of per-scene code (dcsg_stencil_spec) and by the A/B forms (-DDCSG_SWEEP_FORMS)
+    if (c->variant < 4 && !no_rows && (d_nrm || (d_sdf && getenv("DCSG_SWEEP_FORM")))) {
         // the answer depends on the lattice alone: remembered for the last one (a bench or a slab loop sweeps the same
         // lattice again and again, and 3 (res+1) volatile float operations are microseconds of host time per launch)
         if (!c->nz_valid || memcmp(&c->nz_lattice, &L, sizeof(L)) != 0) {

@@ -1022,14 +1022,20 @@ __device__ __forceinline__ bool dcsg_spec_odd(float v) { return !(__builtin_fabs
 
 // dcsg_stencil for the specialised scene module (K = -1 in the kernel bodies below).  LATTICE: the coordinates are
 // lattice positions of a box the host has checked to be finite, so only -0.0 can be odd, and only for the stencil.
+// no_neg_zero (LATTICE only, wave-uniform): the host has checked that no coordinate of the lattice is -0.0
+// (DCSG_SWEEP_NO_NEG_ZERO), so the per-pass test is skipped (3 vector instructions of the fused sweep's 150 per point).
 template <bool LATTICE = false>
 __device__ __forceinline__ void dcsg_stencil_spec(float x, float y, float z, bool want_sdf, bool want_normal, float& sdf,
-                                                  float& nx, float& ny, float& nz)
+                                                  float& nx, float& ny, float& nz, bool no_neg_zero = false)
 {
-    const bool odd = LATTICE ? (want_normal && (dcsg_is_neg_zero(x) || dcsg_is_neg_zero(y) || dcsg_is_neg_zero(z)))
-                             : (dcsg_spec_odd(x) || dcsg_spec_odd(y) || dcsg_spec_odd(z));
     const float e = (float)K2_NORMAL_EPSILON;
-    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
+    bool exact_path = false;
+    if (!(LATTICE && no_neg_zero)) {
+        const bool odd = LATTICE ? (want_normal && (dcsg_is_neg_zero(x) || dcsg_is_neg_zero(y) || dcsg_is_neg_zero(z)))
+                                 : (dcsg_spec_odd(x) || dcsg_spec_odd(y) || dcsg_spec_odd(z));
+        exact_path = __builtin_amdgcn_ballot_w64(odd) != 0ull;
+    }
+    if (exact_path) {
         const float zero = 0.0f;  // v+dx adds +0.0 on the other axes, v-dx subtracts it (k2.cl:167-173)
         if (want_sdf || !want_normal) sdf = dcsg_spec_exact(x, y, z);
         if (want_normal) {
@@ -1353,6 +1359,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
     const float* ax = dcsg_stage_axes<XO>(L, axes_off);
     const bool want_sdf = MODE == 0 ? sdf_out != nullptr : true;
     const bool want_nrm = MODE == 0 ? nrm_out != nullptr : MODE == 3;
+    const bool no_neg_zero = (flags & DCSG_SWEEP_NO_NEG_ZERO) != 0u;  // host-checked: no -0.0 coordinate on this lattice
 #if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
     // one merged guard per lattice point (dcsg_stencil_spec_merged): standard brushes, no -0.0 coordinate on the lattice
     const bool merged = K < 0 && (flags & DCSG_SWEEP_NO_NEG_ZERO) && (flags & DCSG_SWEEP_MERGED) && dcsg_spec_row4_ok();
@@ -1441,7 +1448,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             if (MODE == 3 && merged) dcsg_stencil_spec_merged(xrow[k * DCSG_WAVE], y, z, sd, nx, ny, nz);
             else
 #endif
-                dcsg_stencil_spec<true>(xrow[k * DCSG_WAVE], y, z, true, MODE == 3, sd, nx, ny, nz);
+                dcsg_stencil_spec<true>(xrow[k * DCSG_WAVE], y, z, true, MODE == 3, sd, nx, ny, nz, no_neg_zero);
 #endif
             DCSG_STORE_GATE(sd, nx, ny, nz) {
                 if (MODE == 3) {
@@ -1494,7 +1501,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                 if (MODE == 3 && merged) dcsg_stencil_spec_merged(x, y, z, sd, nx, ny, nz);
                 else
 #endif
-                    dcsg_stencil_spec<true>(x, y, z, want_sdf, want_nrm, sd, nx, ny, nz);
+                    dcsg_stencil_spec<true>(x, y, z, want_sdf, want_nrm, sd, nx, ny, nz, no_neg_zero);
 #endif
 #endif
             } else {

@@ -332,6 +332,24 @@ def test_interpreter_lattice_sweeps_bit_exact(ev, oracle, name, env, monkeypatch
         assert np.array_equal(bits(gs3), bits(ws[res // 3:res // 3 + 9]))
 
 
+@pytest.mark.parametrize("name", ["sphere", "design1", "design2"])
+def test_fused_sweep_with_and_without_the_host_neg_zero_check(ev, oracle, name, monkeypatch):
+    """The host tells the SDF + normal sweep of per-scene code that no lattice coordinate is -0.0 (DCSG_SWEEP_NO_NEG_ZERO),
+    and the kernel then skips its per-pass test for one; with the hint withheld (DCSG_NO_ROWS) it tests every pass.
+    Same bits both ways, equal to the oracle's."""
+    load(ev, name)
+    assert ev.scene_info()["interpreter"] == 3, ev.scene_info()
+    osc = oracle.Scene.from_dir(scene_dir(name))
+    center, diameter, _ = osc.estimate_bounding_box(10.0)
+    c, d, res = [center[0] + 0.0131, center[1] - 0.0077, center[2] + 0.0253], diameter[0] * 1.037, 96
+    ws, wn = osc.eval_lattice(c, d, res)
+    gs, gn = ev.eval_lattice(c, d, res)
+    assert np.array_equal(bits(gs), bits(ws)) and np.array_equal(bits(gn), bits(wn))
+    monkeypatch.setenv("DCSG_NO_ROWS", "1")
+    hs, hn = ev.eval_lattice(c, d, res)
+    assert np.array_equal(bits(hs), bits(ws)) and np.array_equal(bits(hn), bits(wn))
+
+
 LIGHT_DESIGNS = {
     # standard brushes only, at most four object evaluations: what the row kernels (dcsg_sweep_rows) are generated for
     "sphere_offset": "draw(sphere_brush, Transform.initial(np.array([0.31, -0.17, 0.08]), 0.4, -0.7, 1.1, np.array([0.9, 0.6, 0.75])))",
