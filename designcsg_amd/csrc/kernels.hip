@@ -399,6 +399,7 @@ __device__ __forceinline__ float dcsg_div_by(float n, float d, float r1)
     return __builtin_fmaf(e2, r1, q);
 }
 
+#define DCSG_KEY_ORDINARY (2u * 0x21800000u - 2u)  // dcsg_component_key of 2^-60
 #ifdef DCSG_RELAXED
 __device__ __forceinline__ void dcsg_normalize(float& x, float& y, float& z)
 {
@@ -422,22 +423,32 @@ __device__ __forceinline__ void dcsg_finish_normal(float Dx, float Dy, float Dz,
 // equal (one 64-point pass in eight at 513 points per row with the box centred on a sphere) -- and harmless: 0 * r1 = 0,
 // the residual is 0, the quotient is 0 (the sign of a -0 numerator is put back by the copysign; for every other
 // numerator it is a no-op, the divisor being positive).
+// 2 |c| - 2 with |c| as an integer (one v_lshl_add_u32: the shift drops the sign), zeros wrapped to the top:
+// key >= DCSG_KEY_ORDINARY <=> c is a zero or at least 2^-60 in magnitude
 __device__ __forceinline__ unsigned int dcsg_component_key(float c)
 {
-    return (__float_as_uint(c) & 0x7fffffffu) - 1u;  // |c| as an integer, zeros wrapped to the top: key >= bits(2^-60) - 1 <=> ordinary
+    return (__float_as_uint(c) << 1) - 2u;
 }
 __device__ __forceinline__ bool dcsg_normalize_fast(float& x, float& y, float& z, float& len)
 {
-    len = dcsg_sqrt(x * x + y * y + z * z);
-    const float hi = 0x1p60f;
+    // the length's square root (dcsg_sqrt) written out, its operand test and the length's range test folded into ONE
+    // unsigned range test of the estimate g: 2^-48 <= g < 2^60 (g is within an ulp of the root, so the root is positive and
+    // at most 2^60; NaN, zero, tiny and huge squared lengths all fall outside -- two compares and a branch fewer per point
+    // than testing the root's operand, then 0 < len <= 2^60).
     // components are at most len (1 + 2^-22) in magnitude; a tiny, huge or NaN operand anywhere in the wave sends the
-    // wave through the plain divisions (a NaN component makes len NaN, which fails len <= hi; the zero vector has
-    // len 0 and is left to the plain path, which returns it unchanged)
+    // wave through the plain divisions (a NaN component makes g NaN; the zero vector has g NaN too and is left to the
+    // plain path, which returns it unchanged)
+    const float q = x * x + y * y + z * z;
+    const float ry = __builtin_amdgcn_rsqf(q), g = q * ry;
     unsigned int k0 = dcsg_component_key(x), k1 = dcsg_component_key(y), k2 = dcsg_component_key(z);
     unsigned int smallest = k0 < k1 ? k0 : k1;
     smallest = k2 < smallest ? k2 : smallest;
-    const bool plain = !(smallest >= 0x21800000u - 1u && len <= hi && len > 0.0f);
-    if (__builtin_amdgcn_ballot_w64(plain) != 0ull) return false;
+    const bool plain = !(smallest >= DCSG_KEY_ORDINARY && __float_as_uint(g) - 0x27800000u < 0x5d800000u - 0x27800000u);
+    if (__builtin_amdgcn_ballot_w64(plain) != 0ull) {
+        len = dcsg_sqrt(q);
+        return false;
+    }
+    len = __builtin_fmaf(__builtin_fmaf(-g, g, q), 0.5f * ry, g);  // dcsg_sqrt's fast path: same operations, same bits
     float r = __builtin_amdgcn_rcpf(len);
     float e = __builtin_fmaf(-len, r, 1.0f);
     float r1 = __builtin_fmaf(e, r, r);
@@ -496,14 +507,14 @@ struct DcsgNormalAcc {
 };
 __device__ __forceinline__ DcsgNormalAcc dcsg_normal_acc_init(unsigned int gmn, unsigned int gmx)
 {
-    return {gmn, gmx, 0x3f800000u, 0x3f800000u};
+    return {gmn, gmx, 0xffffffffu, 0x3f800000u};
 }
 __device__ __forceinline__ bool dcsg_normal_acc_bad(const DcsgNormalAcc& a)
 {
     // square roots: 2^-48 <= g < inf; normalize (dcsg_normalize_fast): every component a zero or >= 2^-60 in magnitude
     // (dcsg_component_key), length <= 2^60 (a NaN component makes the length NaN, and the zero vector's squared length 0
     // gives rsq(0) * 0 = NaN: both fail the gmx test)
-    return a.gmn < 0x27800000u || a.gmx >= 0x7f800000u || a.smn < 0x21800000u - 1u || a.lmx > 0x5d800000u;
+    return a.gmn < 0x27800000u || a.gmx >= 0x7f800000u || a.smn < DCSG_KEY_ORDINARY || a.lmx > 0x5d800000u;
 }
 __device__ __forceinline__ void dcsg_finish_normal_acc(float Dx, float Dy, float Dz, float& nx, float& ny, float& nz, DcsgNormalAcc& a)
 {
@@ -1238,9 +1249,10 @@ __device__ __forceinline__ void dcsg_store3_lane(float* base, unsigned int lane,
 {
     base = dcsg_uniform_ptr(base);
     dcsg_store_f3 n3 = {a, b, c};
-    // the s_nop is the wait state a VALU write of the data registers of a > 8-byte store needs (the compiler's hazard
-    // recogniser does not look inside asm)
-    asm volatile("global_store_dwordx3 %0, %1, %2 nt\n\ts_nop 0" ::"v"(lane * 12u), "v"(n3), "s"(base));
+    // the s_nop gives the TWO wait states gfx940-class chips need between a store of more than 8 bytes and a VALU write of its
+    // data registers (the compiler's hazard recogniser does not look inside asm; with one wait state Design2's sweep stored
+    // the NEXT pass's "nx = 0" for a few lanes -- caught by test_lattice_sweep_bit_exact)
+    asm volatile("global_store_dwordx3 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane * 12u), "v"(n3), "s"(base));
 }
 #endif
 // A/B builds only (timing, wrong output): -DDCSG_EXPERIMENT_NOSTORE runs the sweeps' arithmetic WITHOUT their store stream --
