@@ -1221,38 +1221,50 @@ __device__ __forceinline__ void dcsg_wave_advance(unsigned int n1, unsigned int&
 // fused 513^3 0.458 -> 0.450 ms, 1025^3 3.54 -> 3.47 (profiles/r03_ab/r03_ab_stores2.txt, r03_ab_saddr.txt).  Used by the
 // SDF + normal sweep of per-scene code only: the SDF-only sweep (+3-4 %) and the interpreters (+1 %) were slower with it.
 // `base` MUST be wave-uniform.
-// No "memory" clobber: no sweep reads the lattice back, and the clobber would order the passes' LDS reads behind the stores.
 #ifdef DCSG_NO_SADDR_STORES  // A/B builds
-__device__ __forceinline__ void dcsg_store_lane(float* base, unsigned int lane, float v) { DCSG_STREAM_STORE(v, base + lane); }
-__device__ __forceinline__ void dcsg_store3_lane(float* base, unsigned int lane, float a, float b, float c)
+__device__ __forceinline__ void dcsg_store_lane(float* base, unsigned int& lane4, float v) { DCSG_STREAM_STORE(v, base + lane4 / 4u); }
+__device__ __forceinline__ void dcsg_store3_lane(float* base, unsigned int& lane12, float a, float b, float c)
 {
-    DCSG_STREAM_STORE(a, base + lane * 3u);
-    DCSG_STREAM_STORE(b, base + lane * 3u + 1);
-    DCSG_STREAM_STORE(c, base + lane * 3u + 2);
+    DCSG_STREAM_STORE(a, base + lane12 / 4u);
+    DCSG_STREAM_STORE(b, base + lane12 / 4u + 1);
+    DCSG_STREAM_STORE(c, base + lane12 / 4u + 2);
 }
 #else
-typedef float dcsg_store_f3 __attribute__((ext_vector_type(3)));
-// SGPR copy of a wave-uniform pointer (folds away where the compiler already knows the value to be uniform)
-__device__ __forceinline__ float* dcsg_uniform_ptr(float* p)
+// SGPR copy of a wave-uniform pointer (folds away where the compiler already knows the value to be uniform), made opaque
+// by an empty asm so that the compiler cannot fold "base + lane" back into a loop-carried VGPR pointer: the stores below
+// are then ordinary compiler-generated instructions of the form global_store ... v_off, v_data, s[base:base+1] (all of the
+// chip's hazards -- the two wait states after a dwordx3 store, SGPRs written by v_readfirstlane -- are the compiler's to
+// handle; a hand-written asm store was measured first and needed them spelled out).
+typedef __attribute__((address_space(1))) float* dcsg_global_ptr;  // global memory, as the kernel arguments are
+__device__ __forceinline__ dcsg_global_ptr dcsg_uniform_ptr(float* p)
 {
     const unsigned long long u = (unsigned long long)p;
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)u);
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(u >> 32));
-    return (float*)(((unsigned long long)hi << 32) | lo);
+    dcsg_global_ptr q = (dcsg_global_ptr)(((unsigned long long)hi << 32) | lo);
+    asm("" : "+s"(q));
+    return q;
 }
-__device__ __forceinline__ void dcsg_store_lane(float* base, unsigned int lane, float v)
+typedef __attribute__((address_space(1))) char* dcsg_global_bytes;
+// the lane's byte offset: loop-invariant (one VGPR across the passes), made opaque where it is used so that its zero-extension
+// stays next to the store and the instruction selector sees "SGPR base + zext(32-bit VGPR)"
+// (lane_bytes: the caller's variable, redefined in place -- no copy)
+__device__ __forceinline__ dcsg_global_ptr dcsg_lane_address(float* base, unsigned int& lane_bytes)
 {
-    base = dcsg_uniform_ptr(base);
-    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(lane * 4u), "v"(v), "s"(base));
+    asm volatile("" : "+v"(lane_bytes));
+    return (dcsg_global_ptr)((dcsg_global_bytes)dcsg_uniform_ptr(base) + lane_bytes);
 }
-__device__ __forceinline__ void dcsg_store3_lane(float* base, unsigned int lane, float a, float b, float c)
+// lane4 = 4 * lane, lane12 = 12 * lane: variables of the caller that live across its passes
+__device__ __forceinline__ void dcsg_store_lane(float* base, unsigned int& lane4, float v)
 {
-    base = dcsg_uniform_ptr(base);
-    dcsg_store_f3 n3 = {a, b, c};
-    // the s_nop gives the TWO wait states gfx940-class chips need between a store of more than 8 bytes and a VALU write of its
-    // data registers (the compiler's hazard recogniser does not look inside asm; with one wait state Design2's sweep stored
-    // the NEXT pass's "nx = 0" for a few lanes -- caught by test_lattice_sweep_bit_exact)
-    asm volatile("global_store_dwordx3 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane * 12u), "v"(n3), "s"(base));
+    DCSG_STREAM_STORE(v, dcsg_lane_address(base, lane4));
+}
+__device__ __forceinline__ void dcsg_store3_lane(float* base, unsigned int& lane12, float a, float b, float c)
+{
+    dcsg_global_ptr o = dcsg_lane_address(base, lane12);
+    DCSG_STREAM_STORE(a, o);
+    DCSG_STREAM_STORE(b, o + 1);
+    DCSG_STREAM_STORE(c, o + 2);
 }
 #endif
 // A/B builds only (timing, wrong output): -DDCSG_EXPERIMENT_NOSTORE runs the sweeps' arithmetic WITHOUT their store stream --
@@ -1372,6 +1384,7 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
     const bool want_sdf = MODE == 0 ? sdf_out != nullptr : true;
     const bool want_nrm = MODE == 0 ? nrm_out != nullptr : MODE == 3;
     const bool no_neg_zero = (flags & DCSG_SWEEP_NO_NEG_ZERO) != 0u;  // host-checked: no -0.0 coordinate on this lattice
+    unsigned int lane4 = lane * 4u, lane12 = lane * 12u;              // byte offsets of the lane's outputs (dcsg_store_lane)
 #if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
     // one merged guard per lattice point (dcsg_stencil_spec_merged): standard brushes, no -0.0 coordinate on the lattice
     const bool merged = K < 0 && (flags & DCSG_SWEEP_NO_NEG_ZERO) && (flags & DCSG_SWEEP_MERGED) && dcsg_spec_row4_ok();
@@ -1464,8 +1477,8 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
 #endif
             DCSG_STORE_GATE(sd, nx, ny, nz) {
                 if (MODE == 3) {
-                    dcsg_store_lane(sdf_out + idx0 + k * DCSG_WAVE, lane, sd);
-                    dcsg_store3_lane(nrm_out + ((size_t)idx0 + k * DCSG_WAVE) * 3, lane, nx, ny, nz);
+                    dcsg_store_lane(sdf_out + idx0 + k * DCSG_WAVE, lane4, sd);
+                    dcsg_store3_lane(nrm_out + ((size_t)idx0 + k * DCSG_WAVE) * 3, lane12, nx, ny, nz);
                 } else {
                     DCSG_STREAM_STORE(sd, (sdf_out + idx0) + lane + k * DCSG_WAVE);
                 }
@@ -1522,8 +1535,8 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             // write-once streaming output: non-temporal stores (nothing in this kernel reads the lattice back)
             DCSG_STORE_GATE(sd, nx, ny, nz) {
                 if (K < 0 && MODE == 3) {
-                    dcsg_store_lane(sdf_out + at, lane, sd);
-                    dcsg_store3_lane(nrm_out + (size_t)at * 3, lane, nx, ny, nz);
+                    dcsg_store_lane(sdf_out + at, lane4, sd);
+                    dcsg_store3_lane(nrm_out + (size_t)at * 3, lane12, nx, ny, nz);
                 } else {
                     // wave-uniform base + lane: the store addresses cost no per-lane multiplies
                     if (want_sdf) DCSG_STREAM_STORE(sd, (sdf_out + at) + lane);
