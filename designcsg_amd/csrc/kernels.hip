@@ -1255,21 +1255,6 @@ __device__ __forceinline__ dcsg_global_ptr dcsg_lane_address(float* base, unsign
     return (dcsg_global_ptr)((dcsg_global_bytes)dcsg_uniform_ptr(base) + lane_bytes);
 }
 // lane4 = 4 * lane, lane12 = 12 * lane: variables of the caller that live across its passes
-#define DCSG_STORE_BITS "nt"
-#endif
-__device__ __forceinline__ void dcsg_store_lane(float* base, unsigned int& lane4, float v)
-{
-    dcsg_global_ptr b = dcsg_uniform_ptr(base);
-    asm volatile("global_store_dword %0, %1, %2 " DCSG_STORE_BITS ::"v"(lane4), "v"(v), "s"(b));
-}
-__device__ __forceinline__ void dcsg_store3_lane(float* base, unsigned int& lane12, float a, float b, float c)
-{
-    typedef float f3 __attribute__((ext_vector_type(3)));
-    dcsg_global_ptr o = dcsg_uniform_ptr(base);
-    f3 n3 = {a, b, c};
-    asm volatile("s_nop 4\n\tglobal_store_dwordx3 %0, %1, %2 " DCSG_STORE_BITS "\n\ts_nop 1" ::"v"(lane12), "v"(n3), "s"(o));
-}
-#else
 __device__ __forceinline__ void dcsg_store_lane(float* base, unsigned int& lane4, float v)
 {
     DCSG_STREAM_STORE(v, dcsg_lane_address(base, lane4));
