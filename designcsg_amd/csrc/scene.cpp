@@ -501,13 +501,39 @@ void build_blob(Scene& s, bool null_brush_is_const)
         s.blob.push_back(f2u(s.pos[3 * i + 1]));
         s.blob.push_back(f2u(s.pos[3 * i + 2]));
         s.blob.push_back((uint32_t)s.shape[i] | ((uint32_t)s.material[i] << 8));  // brush id, material id
-        // Lipschitz bound of v -> (dot(v-o,right), dot(v-o,up), dot(v-o,forward)): the spectral norm of the matrix
-        // with those rows is at most its Frobenius norm (rounded up); used by the tile culling only.
-        double fro = 0;
-        for (int k = 0; k < 3; k++)
-            fro += (double)s.right[3 * i + k] * s.right[3 * i + k] + (double)s.up[3 * i + k] * s.up[3 * i + k] +
-                   (double)s.fwd[3 * i + k] * s.fwd[3 * i + k];
-        float lip = (float)(std::sqrt(fro) * (1.0 + 1e-6)) + 1e-30f;
+        // Lipschitz bound of v -> (dot(v-o,right), dot(v-o,up), dot(v-o,forward)), used by the tile culling only: the
+        // spectral norm of the matrix M with those rows = sqrt of the largest eigenvalue of M^T M (closed form for a
+        // symmetric 3 x 3 matrix, in double, rounded up by 1e-6), never more than the Frobenius norm rounds 1-2 used --
+        // up to sqrt(3) smaller for evenly scaled objects, and every margin of the culling is proportional to it.
+        const float* rows[3] = {&s.right[3 * i], &s.up[3 * i], &s.fwd[3 * i]};
+        double a[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, fro = 0;
+        for (int r = 0; r < 3; r++)
+            for (int u = 0; u < 3; u++) {
+                fro += (double)rows[r][u] * rows[r][u];
+                for (int v = 0; v < 3; v++) a[u][v] += (double)rows[r][u] * (double)rows[r][v];
+            }
+        double top = fro;  // trace of M^T M: an upper bound of its largest eigenvalue, and the fallback
+        const double p1 = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        if (p1 == 0.0) {
+            top = std::max(a[0][0], std::max(a[1][1], a[2][2]));
+        } else {
+            const double q = (a[0][0] + a[1][1] + a[2][2]) / 3.0;
+            const double p2 = (a[0][0] - q) * (a[0][0] - q) + (a[1][1] - q) * (a[1][1] - q) + (a[2][2] - q) * (a[2][2] - q) + 2.0 * p1;
+            const double pp = std::sqrt(p2 / 6.0);
+            if (pp > 0.0 && std::isfinite(pp)) {
+                double b[3][3];
+                for (int u = 0; u < 3; u++)
+                    for (int v = 0; v < 3; v++) b[u][v] = (a[u][v] - (u == v ? q : 0.0)) / pp;
+                double det = b[0][0] * (b[1][1] * b[2][2] - b[1][2] * b[2][1]) - b[0][1] * (b[1][0] * b[2][2] - b[1][2] * b[2][0]) +
+                             b[0][2] * (b[1][0] * b[2][1] - b[1][1] * b[2][0]);
+                double rr = 0.5 * det;
+                rr = rr < -1.0 ? -1.0 : (rr > 1.0 ? 1.0 : rr);
+                const double e = q + 2.0 * pp * std::cos(std::acos(rr) / 3.0);
+                if (std::isfinite(e) && e > 0.0 && e < top) top = e;
+            }
+        }
+        if (!(top <= fro)) top = fro;  // NaN / overflow: the Frobenius bound
+        float lip = (float)(std::sqrt(top) * (1.0 + 1e-6)) + 1e-30f;
         const std::vector<float>* axes[3] = {&s.right, &s.up, &s.fwd};
         int ai = 0;
         for (auto* a : axes) {
