@@ -972,6 +972,16 @@ __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, 
     return k;
 }
 
+// Scenes whose root accumulator is a plain union (scene flag bit 1: PUSH, then T_min steps and groups joined by T_min): the
+// result is the minimum of the items' values, ties going to the LAST of the equal ones, whatever the order of the rest -- so
+// an item whose lower bound lies above the smallest UPPER bound of all items (not only of those before it in the program,
+// which is what the prefix scan knows) is strictly larger than some other item everywhere in the tile, can neither be the
+// minimum nor take part in a tie, and is dropped.  With objects in random order the prefix rule keeps every "record so
+// far" (about ln n of them) besides the ones that matter.  Returns that bound for one lane's item (+inf for other items).
+__device__ __forceinline__ float dcsg_top_min_upper(int op, float ub)
+{
+    return (op == SOP_PUSH || op == SOP_ACC_MIN) ? ub : __builtin_inff();
+}
 // Builds the wave's active-step list for the tile that contains the valid lanes' points (x,y,z); `pad` is
 // added to every half extent (the stencil's epsilon).  Returns the number of steps kept (wave-uniform).
 __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool valid, float x, float y, float z, float pad,
@@ -986,6 +996,17 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
     float hx = 0.5f * (x1 - x0) + pad, hy = 0.5f * (y1 - y0) + pad, hz = 0.5f * (z1 - z0) + pad;
     float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
     const int n = s.n_items;
+    float top_upper = inf;  // plain unions: the smallest upper bound of all items (dcsg_top_min_upper)
+    if (s.flags & 2) {
+        for (int base = 0; base < n; base += DCSG_WAVE) {
+            int op, first, count;
+            float lb, ub;
+            unsigned long long imask;
+            dcsg_item_clamp(s, base + lane, cx, cy, cz, R, op, lb, ub, first, count, imask);
+            top_upper = fminf(top_upper, dcsg_top_min_upper(op, ub));
+        }
+        top_upper = wave_min_f(top_upper);
+    }
     DcsgClamp2 carry = dcsg_clamp_identity();  // composition of all items of earlier chunks
     int n_active = 0;
     for (int base = 0; base < n; base += DCSG_WAVE) {
@@ -993,12 +1014,16 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
         float lb, ub;
         unsigned long long imask;
         DcsgClamp2 mine = dcsg_item_clamp(s, base + lane, cx, cy, cz, R, op, lb, ub, first, count, imask);
-        DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
-        DcsgClamp2 excl = dcsg_clamp_shfl_up(incl, 1);
-        if (lane == 0) excl = dcsg_clamp_identity();
-        DcsgClamp2 before = dcsg_clamp_compose(carry, excl);
-        // a program starts with PUSH, so the clamp before any accumulate is constant: apply it to 0
-        float lo = fminf(fmaxf(0.0f, before.plo), before.qlo), hi = fminf(fmaxf(0.0f, before.phi), before.qhi);
+        float lo = -inf, hi = top_upper;  // plain unions: the bound of all items, no interval walk
+        DcsgClamp2 incl = mine;
+        if (!(s.flags & 2)) {
+            incl = dcsg_clamp_wave_scan(mine);
+            DcsgClamp2 excl = dcsg_clamp_shfl_up(incl, 1);
+            if (lane == 0) excl = dcsg_clamp_identity();
+            DcsgClamp2 before = dcsg_clamp_compose(carry, excl);
+            // a program starts with PUSH, so the clamp before any accumulate is constant: apply it to 0
+            lo = fminf(fmaxf(0.0f, before.plo), before.qlo), hi = fminf(fmaxf(0.0f, before.phi), before.qhi);
+        }
         bool keep = dcsg_step_keep(op, lb, ub, lo, hi);
         const bool all_steps = count > 64;
         unsigned int sz = keep ? (all_steps ? (unsigned int)count : (unsigned int)__popcll(imask)) : 0u;
@@ -1013,9 +1038,11 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
             }
         }
         n_active += (int)__shfl(inc, DCSG_WAVE - 1, DCSG_WAVE);
-        DcsgClamp2 last = {__shfl(incl.plo, DCSG_WAVE - 1, DCSG_WAVE), __shfl(incl.qlo, DCSG_WAVE - 1, DCSG_WAVE),
-                           __shfl(incl.phi, DCSG_WAVE - 1, DCSG_WAVE), __shfl(incl.qhi, DCSG_WAVE - 1, DCSG_WAVE)};
-        carry = dcsg_clamp_compose(carry, last);
+        if (!(s.flags & 2)) {
+            DcsgClamp2 last = {__shfl(incl.plo, DCSG_WAVE - 1, DCSG_WAVE), __shfl(incl.qlo, DCSG_WAVE - 1, DCSG_WAVE),
+                               __shfl(incl.phi, DCSG_WAVE - 1, DCSG_WAVE), __shfl(incl.qhi, DCSG_WAVE - 1, DCSG_WAVE)};
+            carry = dcsg_clamp_compose(carry, last);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -2406,33 +2433,53 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
     DcsgClamp2 carry = dcsg_clamp_identity();
     int n_active = 0;
     __syncthreads();  // the previous brick's readers are done with the list
+    float top_upper = __builtin_inff();  // plain unions: the smallest upper bound of all items (dcsg_top_min_upper)
+    if (s.flags & 2) {
+        for (int base = 0; base < n; base += DCSG_BLOCK) {
+            int op, first, count;
+            float lb, ub;
+            unsigned long long imask;
+            dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask);
+            top_upper = fminf(top_upper, dcsg_top_min_upper(op, ub));
+        }
+        top_upper = wave_min_f(top_upper);
+        if (lane == 0) wtot[wave] = top_upper;
+        __syncthreads();
+        top_upper = fminf(fminf(wtot[0], wtot[1]), fminf(wtot[2], wtot[3]));
+        __syncthreads();  // wtot is free for the scan below
+    }
     for (int base = 0; base < n; base += DCSG_BLOCK) {
         int op, first, count;
         float lb, ub;
         unsigned long long imask;
         DcsgClamp2 mine = dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask);
-        DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
-        if (lane == DCSG_WAVE - 1) {
-            wtot[4 * wave + 0] = incl.plo;
-            wtot[4 * wave + 1] = incl.qlo;
-            wtot[4 * wave + 2] = incl.phi;
-            wtot[4 * wave + 3] = incl.qhi;
+        float lo = -__builtin_inff(), hi = top_upper;  // plain unions: the bound of all items, no interval walk
+        const bool walk = !(s.flags & 2);              // block-uniform
+        if (walk) {
+            DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
+            if (lane == DCSG_WAVE - 1) {
+                wtot[4 * wave + 0] = incl.plo;
+                wtot[4 * wave + 1] = incl.qlo;
+                wtot[4 * wave + 2] = incl.phi;
+                wtot[4 * wave + 3] = incl.qhi;
+            }
+            __syncthreads();
+            DcsgClamp2 pre = carry;  // everything before this wave: earlier chunks, then earlier waves of this chunk
+            for (int w = 0; w < wave; w++)
+                pre = dcsg_clamp_compose(pre, {wtot[4 * w], wtot[4 * w + 1], wtot[4 * w + 2], wtot[4 * w + 3]});
+            DcsgClamp2 excl = dcsg_clamp_shfl_up(incl, 1);
+            if (lane == 0) excl = dcsg_clamp_identity();
+            DcsgClamp2 before = dcsg_clamp_compose(pre, excl);
+            lo = fminf(fmaxf(0.0f, before.plo), before.qlo), hi = fminf(fmaxf(0.0f, before.phi), before.qhi);
         }
-        __syncthreads();
-        DcsgClamp2 pre = carry;  // everything before this wave: earlier chunks, then earlier waves of this chunk
-        for (int w = 0; w < wave; w++)
-            pre = dcsg_clamp_compose(pre, {wtot[4 * w], wtot[4 * w + 1], wtot[4 * w + 2], wtot[4 * w + 3]});
-        DcsgClamp2 excl = dcsg_clamp_shfl_up(incl, 1);
-        if (lane == 0) excl = dcsg_clamp_identity();
-        DcsgClamp2 before = dcsg_clamp_compose(pre, excl);
-        float lo = fminf(fmaxf(0.0f, before.plo), before.qlo), hi = fminf(fmaxf(0.0f, before.phi), before.qhi);
         bool keep = dcsg_step_keep(op, lb, ub, lo, hi);
         const bool all_steps = count > 64;
         unsigned int sz = keep ? (all_steps ? (unsigned int)count : (unsigned int)__popcll(imask)) : 0u;
         unsigned int inc = wave_scan_incl(sz);
         if (lane == DCSG_WAVE - 1) wcnt[wave] = (int)inc;
-        for (int w = 0; w < DCSG_BLOCK / DCSG_WAVE; w++)
-            carry = dcsg_clamp_compose(carry, {wtot[4 * w], wtot[4 * w + 1], wtot[4 * w + 2], wtot[4 * w + 3]});
+        if (walk)
+            for (int w = 0; w < DCSG_BLOCK / DCSG_WAVE; w++)
+                carry = dcsg_clamp_compose(carry, {wtot[4 * w], wtot[4 * w + 1], wtot[4 * w + 2], wtot[4 * w + 3]});
         __syncthreads();
         unsigned int off = (unsigned int)n_active + inc - sz;
         for (int w = 0; w < wave; w++) off += (unsigned int)wcnt[w];

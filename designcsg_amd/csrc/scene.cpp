@@ -488,7 +488,16 @@ void build_blob(Scene& s, bool null_brush_is_const)
     s.blob.push_back((uint32_t)s.n_prog);
     s.blob.push_back((uint32_t)s.n_objects);
     s.blob.push_back((uint32_t)s.n_regs);
-    s.blob.push_back(null_brush_is_const ? 1u : 0u);
+    // flags: bit 0 = the null brush is a constant; bit 1 = the root accumulator sees nothing but PUSH (first), hard unions
+    // (ACC_MIN, groups joined by POP_MIN) and the final EXPORT -- the tile culling may then bound it by the smallest upper
+    // bound of ALL items, not only of those before a step (kernels.hip, dcsg_top_min_upper)
+    bool top_min = s.n_items > 1;
+    for (int i = 0; i < s.n_items && top_min; i++) {
+        const int op = s.items[4 * i + 2];
+        // kernels.hip: SOP_PUSH 32, SOP_ACC_MIN 33, SOP_POP_MIN 36, SOP_EXPORT_TOP 39 (the enum of optimise_program)
+        top_min = (i == 0 && op == 32) || (i > 0 && (op == 33 || op == 36 || op == 39));
+    }
+    s.blob.push_back((null_brush_is_const ? 1u : 0u) | (top_min ? 2u : 0u));
     s.blob.push_back((uint32_t)s.n_stack_prog);
     s.blob.push_back((uint32_t)s.stack_depth);
     s.blob.push_back((uint32_t)s.n_items);
