@@ -2434,6 +2434,9 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
     int n_active = 0;
     __syncthreads();  // the previous brick's readers are done with the list
     float top_upper = __builtin_inff();  // plain unions: the smallest upper bound of all items (dcsg_top_min_upper)
+    // ... and the items' lower bounds, kept in the work area behind the counters for the pass that writes the list (the area
+    // holds 12 bytes per step, Scene::lds_bytes: 2 for the list, 4 here)
+    float* lower = reinterpret_cast<float*>(wcnt + 4);
     if (s.flags & 2) {
         for (int base = 0; base < n; base += DCSG_BLOCK) {
             int op, first, count;
@@ -2441,6 +2444,7 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
             unsigned long long imask;
             dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask);
             top_upper = fminf(top_upper, dcsg_top_min_upper(op, ub));
+            if (base + (int)threadIdx.x < n) lower[base + threadIdx.x] = lb;
         }
         top_upper = wave_min_f(top_upper);
         if (lane == 0) wtot[wave] = top_upper;
@@ -2452,9 +2456,23 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
         int op, first, count;
         float lb, ub;
         unsigned long long imask;
-        DcsgClamp2 mine = dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask);
+        const bool walk = !(s.flags & 2);  // block-uniform
+        DcsgClamp2 mine = dcsg_clamp_identity();
+        bool have = false;
+        if (!walk) {  // plain unions: a single step's bound was computed above; groups are walked again for their step masks
+            const int i = base + (int)threadIdx.x;
+            op = -1, lb = ub = 0.0f, first = count = 0, imask = 1ull;
+            have = i >= n;
+            if (i < n) {
+                const int4 it = s.items[i];
+                if (it.y == 1) {
+                    first = it.x, count = 1, op = it.z, lb = lower[i];
+                    have = true;
+                }
+            }
+        }
+        if (!have) mine = dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask);
         float lo = -__builtin_inff(), hi = top_upper;  // plain unions: the bound of all items, no interval walk
-        const bool walk = !(s.flags & 2);              // block-uniform
         if (walk) {
             DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
             if (lane == DCSG_WAVE - 1) {

@@ -161,7 +161,9 @@ size_t Scene::lds_bytes() const
 {
     // blob + generic interpreter stack + the culling kernels' work area: per step LB, UB (f32), list entry (u16),
     // opcode (u8) and a counter -- also large enough for the 4 per-wave u16 lists of the projection kernel
-    size_t lists = (((size_t)n_stack_prog + 7) & ~(size_t)7) * 12 + 16;
+    // (block list: 2 bytes per step + 80 bytes of wave totals + 4 per item for the lower bounds of a plain union: the 80 spare
+    // bytes keep that inside the area for the shortest programs too)
+    size_t lists = (((size_t)n_stack_prog + 7) & ~(size_t)7) * 12 + 16 + 80;
     return blob.size() * 4 + (size_t)n_regs * DCSG_BLOCK * sizeof(float) + ((lists + 15) & ~(size_t)15);
 }
 
