@@ -1002,7 +1002,8 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
             int op, first, count;
             float lb, ub;
             unsigned long long imask;
-            dcsg_item_clamp(s, base + lane, cx, cy, cz, R, op, lb, ub, first, count, imask);
+            const int i = base + lane;  // order-free: the items sorted by brush (items[i].w)
+            dcsg_item_clamp(s, i < n ? s.items[i].w : n, cx, cy, cz, R, op, lb, ub, first, count, imask);
             top_upper = fminf(top_upper, dcsg_top_min_upper(op, ub));
         }
         top_upper = wave_min_f(top_upper);
@@ -2442,9 +2443,11 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
             int op, first, count;
             float lb, ub;
             unsigned long long imask;
-            dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask);
+            // order-free: thread i bounds item items[i].w (the items sorted by brush: one brush's code per wave)
+            const int i = base + (int)threadIdx.x, j = i < n ? s.items[i].w : n;
+            dcsg_item_clamp(s, j, cx, cy, cz, R, op, lb, ub, first, count, imask);
             top_upper = fminf(top_upper, dcsg_top_min_upper(op, ub));
-            if (base + (int)threadIdx.x < n) lower[base + threadIdx.x] = lb;
+            if (j < n) lower[j] = lb;
         }
         top_upper = wave_min_f(top_upper);
         if (lane == 0) wtot[wave] = top_upper;

@@ -386,10 +386,23 @@ void optimise_program(Scene& s)
                     fine = false;  // incl. smooth accumulates or SET_K at root level
                 }
             }
-            if (fine)
+            if (fine) {
                 s.n_items = (int)(s.items.size() / 4);
-            else
+                // items[i].w: the item thread i bounds in the culling's order-free first pass of a plain union
+                // (kernels.hip, dcsg_top_min_upper) -- the items sorted by brush, so that the lanes of a wave run
+                // through ONE brush's code instead of all of them under exec masks
+                std::vector<int> order(s.n_items);
+                for (int i = 0; i < s.n_items; i++) order[i] = i;
+                auto key = [&](int i) {
+                    const int first = s.items[4 * i], count = s.items[4 * i + 1], op = s.items[4 * i + 2];
+                    if (count != 1 || op == EXPORT_TOP) return 1 << 20;
+                    return (int)(q[4 * (size_t)first + 1] & 0xff);  // the step's brush
+                };
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+                for (int i = 0; i < s.n_items; i++) s.items[4 * i + 3] = order[i];
+            } else {
                 s.items.clear();
+            }
         }
     }
     // ---- liveness renaming ---------------------------------------------------------------------
