@@ -984,8 +984,14 @@ __device__ __forceinline__ float dcsg_top_min_upper(int op, float ub)
 }
 // Builds the wave's active-step list for the tile that contains the valid lanes' points (x,y,z); `pad` is
 // added to every half extent (the stencil's epsilon).  Returns the number of steps kept (wave-uniform).
+// `grow` (a fraction of the tile's largest half extent) widens the tile so that the list stays valid while the points move:
+// `reach`, when given, receives the tile's centre and the half extents within which a POINT may lie (its stencil then stays
+// inside the tile the bounds were taken over).
+struct DcsgTileReach {
+    float cx, cy, cz, ax, ay, az;
+};
 __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool valid, float x, float y, float z, float pad,
-                                                      unsigned short* list)
+                                                      unsigned short* list, float grow = 0.0f, DcsgTileReach* reach = nullptr)
 {
     const int lane = threadIdx.x & (DCSG_WAVE - 1);
     const float inf = __builtin_inff();
@@ -993,7 +999,11 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
     float y0 = wave_min_f(valid ? y : inf), y1 = wave_max_f(valid ? y : -inf);
     float z0 = wave_min_f(valid ? z : inf), z1 = wave_max_f(valid ? z : -inf);
     float cx = 0.5f * (x0 + x1), cy = 0.5f * (y0 + y1), cz = 0.5f * (z0 + z1);
-    float hx = 0.5f * (x1 - x0) + pad, hy = 0.5f * (y1 - y0) + pad, hz = 0.5f * (z1 - z0) + pad;
+    float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0), hz = 0.5f * (z1 - z0);
+    const float extra = grow * (fmaxf(hx, fmaxf(hy, hz)) + pad);
+    hx += extra, hy += extra, hz += extra;
+    if (reach) *reach = {cx, cy, cz, hx, hy, hz};  // before the stencil's pad: where the points themselves may be
+    hx += pad, hy += pad, hz += pad;
     float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
     const int n = s.n_items;
     float top_upper = inf;  // plain unions: the smallest upper bound of all items (dcsg_top_min_upper)
@@ -2686,8 +2696,12 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
 }
 
 // Projection: consecutive vertices of the triangle buffer come from the same or neighbouring octree leaves,
-// so a wave's 64 vertices form a small cluster; the list is rebuilt every step because the vertices move.
-extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+// so a wave's 64 vertices form a small cluster.  (At least 4 waves per SIMD, i.e. at most 128 VGPRs: with its two descent
+// loops the kernel was allocated 130 and lost a quarter of its waves.)
+#ifndef DCSG_PROJECT_C4_WAVES
+#define DCSG_PROJECT_C4_WAVES 4
+#endif
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, DCSG_PROJECT_C4_WAVES)
 dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ verts, unsigned int n_verts, int steps)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
@@ -2698,15 +2712,40 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
         bool valid = i < n_verts;
         unsigned int j = valid ? i : 0u;
         DcsgDescent d = {verts[(size_t)j * 3 + 0], verts[(size_t)j * 3 + 1], verts[(size_t)j * 3 + 2], 0.0f, 0.0f, 0.0f, false, !valid};
-        for (int k = 0; k < steps; k++) {
-            if (__builtin_amdgcn_ballot_w64(!d.done) == 0ull) break;
-            // the tile is the box of the vertices that are still moving; retired lanes run along and are ignored
-            const float x = d.x, y = d.y, z = d.z;
-            int n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list);
-            float sd, nx, ny, nz;
-            dcsg_stencil<4>(s, x, y, z, true, true, sd, nx, ny, nz, list, n_list);
-            float m = -sd;
-            dcsg_descent_advance(d, x + m * nx, y + m * ny, z + m * nz, k, steps);
+        if (s.flags & 2) {
+            // Plain unions: the tile is the box of the vertices that are still moving, widened by a twentieth of its size, and
+            // the list is built again only when a moving vertex leaves that box or half of the vertices it was built for
+            // have retired (the tile of the rest is smaller, its list shorter) -- the steps shrink fast, so a few lists serve
+            // the whole descent (flat256 1024^3: 12.9 -> 11.6 ms).  Retired lanes run along and are ignored.
+            int n_list = 0, built_for = 0;  // built_for: the number of moving vertices the list was built for
+            DcsgTileReach reach = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < steps; k++) {
+                const unsigned long long moving = __builtin_amdgcn_ballot_w64(!d.done);
+                if (moving == 0ull) break;
+                const float x = d.x, y = d.y, z = d.z;
+                const bool outside = !d.done && !(__builtin_fabsf(x - reach.cx) <= reach.ax && __builtin_fabsf(y - reach.cy) <= reach.ay &&
+                                                  __builtin_fabsf(z - reach.cz) <= reach.az);
+                if (2 * __popcll(moving) <= built_for || __builtin_amdgcn_ballot_w64(outside) != 0ull) {
+                    n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, 0.05f, &reach);
+                    built_for = __popcll(moving);
+                }
+                float sd, nx, ny, nz;
+                dcsg_stencil<4>(s, x, y, z, true, true, sd, nx, ny, nz, list, n_list);
+                float m = -sd;
+                dcsg_descent_advance(d, x + m * nx, y + m * ny, z + m * nz, k, steps);
+            }
+        } else {
+            // Mixed joins at the root: a list per step, over the box of the vertices that are still moving (with these scenes
+            // the per-step list of the shrinking tile was the faster one: grouped256 1024^3 9.9 against 11.3 ms)
+            for (int k = 0; k < steps; k++) {
+                if (__builtin_amdgcn_ballot_w64(!d.done) == 0ull) break;
+                const float x = d.x, y = d.y, z = d.z;
+                int n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list);
+                float sd, nx, ny, nz;
+                dcsg_stencil<4>(s, x, y, z, true, true, sd, nx, ny, nz, list, n_list);
+                float m = -sd;
+                dcsg_descent_advance(d, x + m * nx, y + m * ny, z + m * nz, k, steps);
+            }
         }
         if (valid) {
             verts[(size_t)i * 3 + 0] = d.x;
