@@ -2588,8 +2588,11 @@ __device__ __forceinline__ void dcsg_sweep_c4_body(const uint4* __restrict__ blo
     }
 }
 
+#ifndef DCSG_C4_WAVES
+#define DCSG_C4_WAVES 1  // A/B builds: minimum waves per SIMD asked of the culling sweeps
+#endif
 #define DCSG_SWEEP_C4_KERNEL(NAME, MODE)                                                                               \
-    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                          \
+    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, DCSG_C4_WAVES)                                           \
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first, unsigned int n_points, \
          float* __restrict__ sdf_out, float* __restrict__ nrm_out, int /*axes_off: unused*/, unsigned int /*flags*/)   \
     {                                                                                                                  \
@@ -2633,7 +2636,7 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
 }
 
 // Node-wise sweep with tile culling: the node's box is the tile.
-extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, DCSG_C4_WAVES)
 dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,
                     unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,
                     unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz, int z_own_lo, int z_own_hi,
