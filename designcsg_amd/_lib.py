@@ -56,6 +56,7 @@ PROTOTYPES = {
     "dcsg_set_arbitrary_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dcsg_set_numerics": (C.c_int, [C.c_void_p, C.c_int]),
     "dcsg_scene_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 6),
+    "dcsg_debug_scene_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "dcsg_eval_sdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dcsg_eval_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dcsg_eval_sdf_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

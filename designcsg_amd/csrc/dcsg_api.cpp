@@ -869,6 +869,13 @@ int dcsg_scene_info(const dcsg_ctx* c, int* n_objects, int* n_steps, int* n_slot
     return 0;
 }
 
+int dcsg_debug_scene_flags(const dcsg_ctx* c, int* flags)
+{
+    if (!c || !c->scene_loaded || c->scene.blob.size() < 4) return DCSG_ERR_NO_SCENE;
+    if (flags) *flags = (int)c->scene.blob[3];
+    return 0;
+}
+
 int dcsg_eval_sdf(dcsg_ctx* c, const float* xyz, size_t n, float* out) { return eval_points_host(c, xyz, n, 0, out); }
 int dcsg_eval_normal(dcsg_ctx* c, const float* xyz, size_t n, float* out) { return eval_points_host(c, xyz, n, 1, out); }
 

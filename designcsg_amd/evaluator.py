@@ -102,6 +102,12 @@ class Evaluator:
         return dict(objects=v[0].value, steps=v[1].value, slots=v[2].value, jit=bool(v[3].value),
                     interpreter=v[4].value, stack_depth=v[5].value)
 
+    def scene_flags(self):
+        """Diagnostic: flags word of the scene's device tables (bit 1: the root is a plain union, dcsg.h)."""
+        f = C.c_int()
+        self._ck(self._L.dcsg_debug_scene_flags(self._h, C.byref(f)))
+        return f.value
+
     # ---- Evaluator::setArbitraryData (Evaluator.cpp:213-225) ------------------------------
     def setArbitraryData(self, data, items=None):
         a = np.ascontiguousarray(data, dtype=np.float32)

@@ -255,6 +255,9 @@ int dcsg_expand_lookup_table(const char* lookup_table_txt, uint8_t table[4096], 
  * the largest float q with (float)acos((double)q) > threshold, or -2 if there is none. */
 float dcsg_angle_q_star(float complex_surface_threshold);
 
+/* Diagnostic: the flags word of the loaded scene's device tables (csrc/scene.cpp build_blob): bit 0 = the null brush is a
+ * constant, bit 1 = the root accumulator is a plain union (the tile culling's order-free rule applies). */
+int dcsg_debug_scene_flags(const dcsg_ctx* ctx, int* flags);
 /* Diagnostic: the kernels' correctly rounded square root over a device array (exhaustive GPU test). */
 int dcsg_debug_sqrt_device(dcsg_ctx* ctx, const float* d_in, size_t n, float* d_out, void* stream);
 /* Diagnostic: the tail of get_normal (k2.cl:175-177: gradient scale in double, normalize) as the kernels compute it,

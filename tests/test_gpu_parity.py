@@ -254,6 +254,60 @@ def test_random_scenes(ev, oracle, lookup_table, seed, tmp_path, monkeypatch):
             assert st.mesh.culled[l] == ost.nodes_culled[l] and st.mesh.subdivided[l] == ost.nodes_subdivided[l]
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_plain_union_culling(ev, oracle, lookup_table, seed, tmp_path):
+    """Scenes whose root is a plain union -- single draws and drawn groups (unions and intersections of leaves, joined to
+    the root by a union) -- take the culling kernels' order-free rule: an item is dropped when its lower bound over the
+    tile lies above the smallest upper bound of ALL items (scene flag bit 1, kernels.hip dcsg_top_min_upper), groups are
+    walked for their step masks, the projection keeps its list across steps.  Point evaluation (per-wave lists), lattice
+    sweeps (per-brick lists, SDF + normals and SDF only) and the export against the oracle, bit for bit."""
+    from designcsg_amd.run import run_design
+    rng = np.random.default_rng(77 + seed)
+    brushes = ["sphere_brush", "box_brush", "cylinder_brush"]
+
+    def tf(spread, lo, hi):
+        p, a, sc = rng.uniform(-spread, spread, 3), rng.uniform(0, np.pi, 3), rng.uniform(lo, hi, 3)
+        return "Transform.initial(np.array(%r), %r, %r, %r, np.array(%r))" % (list(np.round(p, 3)), round(a[0], 3), round(a[1], 3),
+                                                                                round(a[2], 3), list(np.round(sc, 3)))
+
+    L = ["from DesignCSG import *", "from designlibrary import *", "import numpy as np", ""]
+    for i in range(40):
+        kind = rng.integers(0, 5)
+        if kind <= 2:
+            L.append("draw(%s, %s)" % (brushes[i % 3], tf(0.8, 0.05, 0.25)))
+        else:
+            fn = "drawUnion" if kind == 3 else "drawIntersection"
+            kids = ", ".join("Component(%s, %s)" % (brushes[rng.integers(3)], tf(0.15, 0.15, 0.35)) for _ in range(int(rng.integers(2, 6))))
+            L.append("%s(%s, transform=%s)" % (fn, kids, tf(0.7, 0.8, 1.2)))
+    L += ["setExportConfig(2.0, 3, 5, 6, np.pi / 4, 50, 16, 512, 4096)", "commit()"]
+    script = tmp_path / "design.py"
+    script.write_text("\n".join(L) + "\n")
+    wd = run_design(str(script), str(tmp_path / "wd"))
+    assert ev.build_from_dir(wd)[0] == 0
+    assert ev.scene_info()["interpreter"] == 4, ev.scene_info()
+    assert ev.scene_flags() & 2                       # the root is a plain union
+    osc = oracle.Scene.from_dir(wd)
+    pts = rng.uniform(-1.5, 1.5, (40_000, 3)).astype(np.float32)
+    assert np.array_equal(bits(ev.eval_sdf_at_points(pts)), bits(osc.eval_sdf(pts)))
+    assert np.array_equal(bits(ev.eval_normal_at_points(pts)), bits(osc.eval_normal(pts)))
+    cfg_txt = open(os.path.join(wd, "exportConfig.txt")).read()
+    ocfg = oracle.parse_export_config(cfg_txt)
+    oc, od, on = osc.estimate_bounding_box(ocfg.bounding_box_half_diameter)
+    assert od[0] > 0
+    for r in (24, 75):
+        gs, gn = ev.eval_lattice(oc, od[0], r)
+        ws, wn = osc.eval_lattice(oc, od[0], r)
+        assert np.array_equal(bits(gs), bits(ws)) and np.array_equal(bits(gn), bits(wn))
+    gs2, _ = ev.eval_lattice(oc, od[0], 75, normals=False)
+    assert np.array_equal(bits(gs2), bits(ws))
+    st = ev.export(cfg_txt)
+    assert list(st.box_center) == oc and st.box_diameter == od[0] and st.interior_points == on
+    raw, _ = osc.get_surface(oc, od[0], ocfg, lookup_table)
+    want = osc.gradient_descent(raw, ocfg.gradient_descent_steps)
+    assert st.triangles == len(want) and st.triangles > 1000
+    assert np.array_equal(sorted_tris(ev.download_triangles()), sorted_tris(want))
+
+
 def test_builtin_bank_equals_jit_bank(ev, oracle):
     """scene.cl = None selects the HIP-native brushes; the generated scene.cl text must agree with them."""
     s = read_scene("flat256")
@@ -277,6 +331,7 @@ def test_lattice_sweep_bit_exact(ev, oracle, name):
     res = 48  # not a power of two: exercises the x/w division path
     if name in ("flat256", "grouped256", "smooth256"):  # hundreds of objects: keep the oracle's share short; culling kernels on the GPU
         assert ev.scene_info()["interpreter"] == 4
+        assert bool(ev.scene_flags() & 2) == (name == "flat256")   # plain union at the root: the order-free culling rule
         for r in (24, 32, 75):   # 76 points per row: bricks clipped at the far faces, quarters of a brick left empty
             gs, gn = ev.eval_lattice(center, diameter[0], r)
             ws, wn = osc.eval_lattice(center, diameter[0], r)
