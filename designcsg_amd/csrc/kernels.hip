@@ -893,6 +893,20 @@ __device__ __forceinline__ void dcsg_step_bounds(const SceneLds& s, const int4& 
     ub = val + m;
 }
 
+// Bounds of the program's steps over a tile, computed ONE STEP PER LANE before the items are walked: a group's leaves are
+// then read back instead of being evaluated one after the other by the group's single lane (grouped256: 16 lanes of a wave
+// walking 16 leaves each -- 256 brush evaluations in sequence on a quarter of the lanes -- became 4 rounds of 64).
+// cols < 0: element e at base[e] (the block list's work area); otherwise the wave's own columns of the generic interpreter's
+// LDS stack (row e / 64, column cols + e % 64 of rows of DCSG_BLOCK floats): nothing else of this wave uses them while a
+// list is being built, and the other waves' columns are theirs.
+struct DcsgStepCache {
+    float* base;
+    int cols;
+};
+__device__ __forceinline__ float* dcsg_step_cache_at(const DcsgStepCache& c, int e)
+{
+    return c.cols < 0 ? c.base + e : c.base + (e >> 6) * DCSG_BLOCK + c.cols + (e & 63);
+}
 // Bounds of top-level item i over the tile (centre cx,cy,cz, radius R) and the clamp it applies to the root
 // accumulator's interval.  A leaf is one accumulate step; a group "PUSH, ACC..., POP_x" is walked step by step
 // (interval arithmetic on its own accumulator) and then acts like an accumulate of its result with the POP's
@@ -902,7 +916,7 @@ __device__ __forceinline__ void dcsg_step_bounds(const SceneLds& s, const int4& 
 // is dropped (groups longer than 64 steps keep all their steps).
 __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, float cx, float cy, float cz, float R, int& op,
                                                       float& lb, float& ub, int& first, int& count,
-                                                      unsigned long long& mask)
+                                                      unsigned long long& mask, const DcsgStepCache* cache = nullptr)
 {
     op = -1;
     lb = ub = 0.0f;
@@ -917,11 +931,29 @@ __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, 
     const float inf = __builtin_inff();
     if (op == SOP_EXPORT_TOP) return k;
     if (count == 1) {
-        dcsg_step_bounds(s, s.stack_steps[first], cx, cy, cz, R, lb, ub);
+        if (cache) lb = *dcsg_step_cache_at(*cache, 2 * first), ub = *dcsg_step_cache_at(*cache, 2 * first + 1);
+        else dcsg_step_bounds(s, s.stack_steps[first], cx, cy, cz, R, lb, ub);
     } else {
         float glo = 0.0f, ghi = 0.0f, gk = 0.0f, gq = 0.0f;
         const bool small = count <= 64;
         mask = small ? (1ull << (count - 1)) : ~0ull;  // the POP always runs
+        // A group that is one fold -- PUSH then T_min steps only, or PUSH then T_max / T_max(-s) steps only -- has the value
+        // min (max) over its leaves whatever their order, ties going to the last of the equal ones: a leaf that lies
+        // strictly above the smallest upper bound (below the largest lower bound) of ALL the group's leaves, not only of
+        // those before it, can neither be that value nor take part in a tie (dcsg_top_min_upper, one level down).  Needs
+        // the steps' bounds twice, so only with the cache.
+        // (which groups are folds is the host's finding: items[i].w = 1 min, 2 max, unless the scene is a plain union at the
+        // root, whose items carry their brush order there)
+        const int fold = (cache && !(s.flags & 2)) ? it.w : 0;
+        float fold_min_ub = inf, fold_max_lb = -inf;
+        if (fold == 1) {
+            for (int j = 0; j < count - 1; j++) fold_min_ub = fminf(fold_min_ub, *dcsg_step_cache_at(*cache, 2 * (first + j) + 1));
+        } else if (fold == 2) {
+            for (int j = 0; j < count - 1; j++) {
+                const float b0 = *dcsg_step_cache_at(*cache, 2 * (first + j)), b1 = *dcsg_step_cache_at(*cache, 2 * (first + j) + 1);
+                fold_max_lb = fmaxf(fold_max_lb, s.stack_steps[first + j].x == SOP_ACC_NEGMAX ? -b1 : b0);
+            }
+        }
         for (int j = 0; j < count - 1; j++) {
             int4 st = s.stack_steps[first + j];
             if (st.x == SOP_SET_K) {  // radius of the smooth joins that follow; always runs
@@ -931,8 +963,9 @@ __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, 
                 continue;
             }
             float b0, b1;
-            dcsg_step_bounds(s, st, cx, cy, cz, R, b0, b1);
-            bool keep = dcsg_step_keep(st.x, b0, b1, glo, ghi, gk);
+            if (cache) b0 = *dcsg_step_cache_at(*cache, 2 * (first + j)), b1 = *dcsg_step_cache_at(*cache, 2 * (first + j) + 1);
+            else dcsg_step_bounds(s, st, cx, cy, cz, R, b0, b1);
+            bool keep = dcsg_step_keep(st.x, b0, b1, fold == 2 ? fmaxf(glo, fold_max_lb) : glo, fold == 1 ? fminf(ghi, fold_min_ub) : ghi, gk);
             if (keep && small) mask |= 1ull << j;
             if (st.x >= SOP_ACC_SMIN) {  // smooth accumulates: unchanged when dropped, else min / max widened by gq
                 if (keep) {
@@ -982,6 +1015,17 @@ __device__ __forceinline__ float dcsg_top_min_upper(int op, float ub)
 {
     return (op == SOP_PUSH || op == SOP_ACC_MIN) ? ub : __builtin_inff();
 }
+// one step's bounds into the cache (steps without an object -- SET_K, POP, EXPORT -- store zeros nobody reads)
+__device__ __forceinline__ void dcsg_cache_step_bounds(const SceneLds& s, const DcsgStepCache& c, int t, float cx, float cy, float cz, float R)
+{
+    if (t >= s.n_stack_steps) return;
+    const int4 st = s.stack_steps[t];
+    float lb = 0.0f, ub = 0.0f;
+    const bool leaf = st.x == SOP_PUSH || (st.x >= SOP_ACC_MIN && st.x <= SOP_ACC_NEGMAX) || (st.x >= SOP_ACC_SMIN && st.x <= SOP_ACC_NEGSMAX);
+    if (leaf) dcsg_step_bounds(s, st, cx, cy, cz, R, lb, ub);
+    *dcsg_step_cache_at(c, 2 * t) = lb;
+    *dcsg_step_cache_at(c, 2 * t + 1) = ub;
+}
 // Builds the wave's active-step list for the tile that contains the valid lanes' points (x,y,z); `pad` is
 // added to every half extent (the stencil's epsilon).  Returns the number of steps kept (wave-uniform).
 // `grow` (a fraction of the tile's largest half extent) widens the tile so that the list stays valid while the points move:
@@ -1018,13 +1062,23 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
         }
         top_upper = wave_min_f(top_upper);
     }
+    // every step's bounds first, one step per lane (scene flag bit 2: the wave's columns of the generic interpreter's stack hold
+    // them), when the items are walked below (plain unions bound each item once, above)
+    DcsgStepCache cache = {reinterpret_cast<float*>(dcsg_lds + s.n_vec4), (int)(threadIdx.x & ~(DCSG_WAVE - 1u))};
+    const bool cached = (s.flags & 6) == 4;
+    if (cached) {
+        for (int t = lane; t < s.n_stack_steps; t += DCSG_WAVE) dcsg_cache_step_bounds(s, cache, t, cx, cy, cz, R);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     DcsgClamp2 carry = dcsg_clamp_identity();  // composition of all items of earlier chunks
     int n_active = 0;
     for (int base = 0; base < n; base += DCSG_WAVE) {
         int op, first, count;
         float lb, ub;
         unsigned long long imask;
-        DcsgClamp2 mine = dcsg_item_clamp(s, base + lane, cx, cy, cz, R, op, lb, ub, first, count, imask);
+        DcsgClamp2 mine = dcsg_item_clamp(s, base + lane, cx, cy, cz, R, op, lb, ub, first, count, imask, cached ? &cache : nullptr);
         float lo = -inf, hi = top_upper;  // plain unions: the bound of all items, no interval walk
         DcsgClamp2 incl = mine;
         if (!(s.flags & 2)) {
@@ -2465,6 +2519,12 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
         top_upper = fminf(fminf(wtot[0], wtot[1]), fminf(wtot[2], wtot[3]));
         __syncthreads();  // wtot is free for the scan below
     }
+    // the walk: every step's bounds first, one step per thread, into the work area (the plain unions' `lower`)
+    DcsgStepCache cache = {lower, -1};
+    if (!(s.flags & 2)) {
+        for (int t = (int)threadIdx.x; t < s.n_stack_steps; t += DCSG_BLOCK) dcsg_cache_step_bounds(s, cache, t, cx, cy, cz, R);
+        __syncthreads();
+    }
     for (int base = 0; base < n; base += DCSG_BLOCK) {
         int op, first, count;
         float lb, ub;
@@ -2484,7 +2544,7 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
                 }
             }
         }
-        if (!have) mine = dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask);
+        if (!have) mine = dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask, walk ? &cache : nullptr);
         float lo = -__builtin_inff(), hi = top_upper;  // plain unions: the bound of all items, no interval walk
         if (walk) {
             DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
@@ -2591,8 +2651,11 @@ __device__ __forceinline__ void dcsg_sweep_c4_body(const uint4* __restrict__ blo
 #ifndef DCSG_C4_WAVES
 #define DCSG_C4_WAVES 1  // A/B builds: minimum waves per SIMD asked of the culling sweeps
 #endif
+#ifndef DCSG_C4D_WAVES
+#define DCSG_C4D_WAVES 1  // A/B builds: the SDF-only culling sweep takes 77 VGPRs (6 waves per SIMD); asking for 7 or 8 makes it spill
+#endif
 #define DCSG_SWEEP_C4_KERNEL(NAME, MODE)                                                                               \
-    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, DCSG_C4_WAVES)                                           \
+    extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, ((MODE) == 1 ? DCSG_C4D_WAVES : DCSG_C4_WAVES))         \
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first, unsigned int n_points, \
          float* __restrict__ sdf_out, float* __restrict__ nrm_out, int /*axes_off: unused*/, unsigned int /*flags*/)   \
     {                                                                                                                  \

@@ -399,7 +399,31 @@ void optimise_program(Scene& s)
                     return (int)(q[4 * (size_t)first + 1] & 0xff);  // the step's brush
                 };
                 std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
-                for (int i = 0; i < s.n_items; i++) s.items[4 * i + 3] = order[i];
+                bool top_min = s.n_items > 1;  // the same test as build_blob's flag bit 1
+                for (int i = 0; i < s.n_items && top_min; i++) {
+                    const int op = s.items[4 * i + 2];
+                    top_min = (i == 0 && op == PUSH) || (i > 0 && (op == ACC_MIN || op == POP_MIN || op == EXPORT_TOP));
+                }
+                for (int i = 0; i < s.n_items; i++) {
+                    if (top_min) {
+                        s.items[4 * i + 3] = order[i];
+                        continue;
+                    }
+                    // otherwise items[i].w: a group that is ONE fold -- 1: PUSH then T_min steps only, 2: PUSH then
+                    // T_max / T_max(-s) steps only -- whose leaves the culling bounds over all of them (dcsg_item_clamp)
+                    const int first = s.items[4 * i], count = s.items[4 * i + 1];
+                    int fold = 0;
+                    if (count > 2 && count <= 64 && OP((size_t)first) == PUSH) {
+                        bool all_min = true, all_max = true;
+                        for (int j = 1; j < count - 1; j++) {
+                            const int op = OP((size_t)(first + j));
+                            all_min = all_min && op == ACC_MIN;
+                            all_max = all_max && (op == ACC_MAX || op == ACC_NEGMAX);
+                        }
+                        fold = all_min ? 1 : (all_max ? 2 : 0);
+                    }
+                    s.items[4 * i + 3] = fold;
+                }
             } else {
                 s.items.clear();
             }
@@ -512,7 +536,10 @@ void build_blob(Scene& s, bool null_brush_is_const)
         // kernels.hip: SOP_PUSH 32, SOP_ACC_MIN 33, SOP_POP_MIN 36, SOP_EXPORT_TOP 39 (the enum of optimise_program)
         top_min = (i == 0 && op == 32) || (i > 0 && (op == 33 || op == 36 || op == 39));
     }
-    s.blob.push_back((null_brush_is_const ? 1u : 0u) | (top_min ? 2u : 0u));
+    // bit 2: the bounds of all steps (2 floats each) fit into one wave's columns of the generic interpreter's LDS stack
+    // (n_regs rows of 64 floats): the per-wave list builder computes them one step per lane (kernels.hip, DcsgStepCache)
+    const bool wave_cache = s.n_items > 0 && 2 * (size_t)s.n_stack_prog <= (size_t)s.n_regs * 64;
+    s.blob.push_back((null_brush_is_const ? 1u : 0u) | (top_min ? 2u : 0u) | (wave_cache ? 4u : 0u));
     s.blob.push_back((uint32_t)s.n_stack_prog);
     s.blob.push_back((uint32_t)s.stack_depth);
     s.blob.push_back((uint32_t)s.n_items);
