@@ -916,7 +916,7 @@ __device__ __forceinline__ float* dcsg_step_cache_at(const DcsgStepCache& c, int
 // is dropped (groups longer than 64 steps keep all their steps).
 __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, float cx, float cy, float cz, float R, int& op,
                                                       float& lb, float& ub, int& first, int& count,
-                                                      unsigned long long& mask, const DcsgStepCache* cache = nullptr)
+                                                      unsigned long long& mask, const DcsgStepCache cache = {nullptr, -1})
 {
     op = -1;
     lb = ub = 0.0f;
@@ -931,7 +931,7 @@ __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, 
     const float inf = __builtin_inff();
     if (op == SOP_EXPORT_TOP) return k;
     if (count == 1) {
-        if (cache) lb = *dcsg_step_cache_at(*cache, 2 * first), ub = *dcsg_step_cache_at(*cache, 2 * first + 1);
+        if (cache.base) lb = *dcsg_step_cache_at(cache, 2 * first), ub = *dcsg_step_cache_at(cache, 2 * first + 1);
         else dcsg_step_bounds(s, s.stack_steps[first], cx, cy, cz, R, lb, ub);
     } else {
         float glo = 0.0f, ghi = 0.0f, gk = 0.0f, gq = 0.0f;
@@ -944,13 +944,13 @@ __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, 
         // the steps' bounds twice, so only with the cache.
         // (which groups are folds is the host's finding: items[i].w = 1 min, 2 max, unless the scene is a plain union at the
         // root, whose items carry their brush order there)
-        const int fold = (cache && !(s.flags & 2)) ? it.w : 0;
+        const int fold = (cache.base && !(s.flags & 2)) ? it.w : 0;
         float fold_min_ub = inf, fold_max_lb = -inf;
         if (fold == 1) {
-            for (int j = 0; j < count - 1; j++) fold_min_ub = fminf(fold_min_ub, *dcsg_step_cache_at(*cache, 2 * (first + j) + 1));
+            for (int j = 0; j < count - 1; j++) fold_min_ub = fminf(fold_min_ub, *dcsg_step_cache_at(cache, 2 * (first + j) + 1));
         } else if (fold == 2) {
             for (int j = 0; j < count - 1; j++) {
-                const float b0 = *dcsg_step_cache_at(*cache, 2 * (first + j)), b1 = *dcsg_step_cache_at(*cache, 2 * (first + j) + 1);
+                const float b0 = *dcsg_step_cache_at(cache, 2 * (first + j)), b1 = *dcsg_step_cache_at(cache, 2 * (first + j) + 1);
                 fold_max_lb = fmaxf(fold_max_lb, s.stack_steps[first + j].x == SOP_ACC_NEGMAX ? -b1 : b0);
             }
         }
@@ -963,7 +963,7 @@ __device__ __forceinline__ DcsgClamp2 dcsg_item_clamp(const SceneLds& s, int i, 
                 continue;
             }
             float b0, b1;
-            if (cache) b0 = *dcsg_step_cache_at(*cache, 2 * (first + j)), b1 = *dcsg_step_cache_at(*cache, 2 * (first + j) + 1);
+            if (cache.base) b0 = *dcsg_step_cache_at(cache, 2 * (first + j)), b1 = *dcsg_step_cache_at(cache, 2 * (first + j) + 1);
             else dcsg_step_bounds(s, st, cx, cy, cz, R, b0, b1);
             bool keep = dcsg_step_keep(st.x, b0, b1, fold == 2 ? fmaxf(glo, fold_max_lb) : glo, fold == 1 ? fminf(ghi, fold_min_ub) : ghi, gk);
             if (keep && small) mask |= 1ull << j;
@@ -1035,7 +1035,7 @@ struct DcsgTileReach {
     float cx, cy, cz, ax, ay, az;
 };
 __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool valid, float x, float y, float z, float pad,
-                                                      unsigned short* list, float grow = 0.0f, DcsgTileReach* reach = nullptr)
+                                                      unsigned short* list, float grow, DcsgTileReach& reach)
 {
     const int lane = threadIdx.x & (DCSG_WAVE - 1);
     const float inf = __builtin_inff();
@@ -1046,7 +1046,7 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
     float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0), hz = 0.5f * (z1 - z0);
     const float extra = grow * (fmaxf(hx, fmaxf(hy, hz)) + pad);
     hx += extra, hy += extra, hz += extra;
-    if (reach) *reach = {cx, cy, cz, hx, hy, hz};  // before the stencil's pad: where the points themselves may be
+    reach = {cx, cy, cz, hx, hy, hz};  // before the stencil's pad: where the points themselves may be
     hx += pad, hy += pad, hz += pad;
     float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
     const int n = s.n_items;
@@ -1078,7 +1078,7 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
         int op, first, count;
         float lb, ub;
         unsigned long long imask;
-        DcsgClamp2 mine = dcsg_item_clamp(s, base + lane, cx, cy, cz, R, op, lb, ub, first, count, imask, cached ? &cache : nullptr);
+        DcsgClamp2 mine = dcsg_item_clamp(s, base + lane, cx, cy, cz, R, op, lb, ub, first, count, imask, {cached ? cache.base : nullptr, cache.cols});
         float lo = -inf, hi = top_upper;  // plain unions: the bound of all items, no interval walk
         DcsgClamp2 incl = mine;
         if (!(s.flags & 2)) {
@@ -2544,7 +2544,7 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
                 }
             }
         }
-        if (!have) mine = dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask, walk ? &cache : nullptr);
+        if (!have) mine = dcsg_item_clamp(s, base + threadIdx.x, cx, cy, cz, R, op, lb, ub, first, count, imask, {walk ? cache.base : nullptr, -1});
         float lo = -__builtin_inff(), hi = top_upper;  // plain unions: the bound of all items, no interval walk
         if (walk) {
             DcsgClamp2 incl = dcsg_clamp_wave_scan(mine);
@@ -2682,7 +2682,8 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
         float x = half_neg + cd * (float)ix;
         float y = half_neg + cd * (float)iy;
         float z = half_neg + cd * (float)iz;
-        int n_list = dcsg_build_active_list(s, true, x, y, z, 0.0f, list);
+        DcsgTileReach unused;
+        int n_list = dcsg_build_active_list(s, true, x, y, z, 0.0f, list, 0.0f, unused);
         float v, u0, u1, u2;
         dcsg_stencil<4>(s, x, y, z, true, false, v, u0, u1, u2, list, n_list);
         if ((double)v < bb_eps) {
@@ -2792,7 +2793,7 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
                 const bool outside = !d.done && !(__builtin_fabsf(x - reach.cx) <= reach.ax && __builtin_fabsf(y - reach.cy) <= reach.ay &&
                                                   __builtin_fabsf(z - reach.cz) <= reach.az);
                 if (2 * __popcll(moving) <= built_for || __builtin_amdgcn_ballot_w64(outside) != 0ull) {
-                    n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, 0.05f, &reach);
+                    n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, 0.05f, reach);
                     built_for = __popcll(moving);
                 }
                 float sd, nx, ny, nz;
@@ -2806,7 +2807,8 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
             for (int k = 0; k < steps; k++) {
                 if (__builtin_amdgcn_ballot_w64(!d.done) == 0ull) break;
                 const float x = d.x, y = d.y, z = d.z;
-                int n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list);
+                DcsgTileReach unused;
+                int n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, 0.0f, unused);
                 float sd, nx, ny, nz;
                 dcsg_stencil<4>(s, x, y, z, true, true, sd, nx, ny, nz, list, n_list);
                 float m = -sd;
