@@ -2779,41 +2779,75 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
         bool valid = i < n_verts;
         unsigned int j = valid ? i : 0u;
         DcsgDescent d = {verts[(size_t)j * 3 + 0], verts[(size_t)j * 3 + 1], verts[(size_t)j * 3 + 2], 0.0f, 0.0f, 0.0f, false, !valid};
-        if (s.flags & 2) {
-            // Plain unions: the tile is the box of the vertices that are still moving, widened by a twentieth of its size, and
-            // the list is built again only when a moving vertex leaves that box or half of the vertices it was built for
-            // have retired (the tile of the rest is smaller, its list shorter) -- the steps shrink fast, so a few lists serve
-            // the whole descent (flat256 1024^3: 12.9 -> 11.6 ms).  Retired lanes run along and are ignored.
-            int n_list = 0, built_for = 0;  // built_for: the number of moving vertices the list was built for
-            DcsgTileReach reach = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            for (int k = 0; k < steps; k++) {
-                const unsigned long long moving = __builtin_amdgcn_ballot_w64(!d.done);
-                if (moving == 0ull) break;
-                const float x = d.x, y = d.y, z = d.z;
-                const bool outside = !d.done && !(__builtin_fabsf(x - reach.cx) <= reach.ax && __builtin_fabsf(y - reach.cy) <= reach.ay &&
-                                                  __builtin_fabsf(z - reach.cz) <= reach.az);
-                if (2 * __popcll(moving) <= built_for || __builtin_amdgcn_ballot_w64(outside) != 0ull) {
-                    n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, 0.05f, reach);
-                    built_for = __popcll(moving);
-                }
-                float sd, nx, ny, nz;
-                dcsg_stencil<4>(s, x, y, z, true, true, sd, nx, ny, nz, list, n_list);
-                float m = -sd;
-                dcsg_descent_advance(d, x + m * nx, y + m * ny, z + m * nz, k, steps);
-            }
-        } else {
-            // Mixed joins at the root: a list per step, over the box of the vertices that are still moving (with these scenes
-            // the per-step list of the shrinking tile was the faster one: grouped256 1024^3 9.9 against 11.3 ms)
+        // Plain unions (scene flag bit 1): the tile is the box of the vertices that are still moving, widened by a twentieth of
+        // its size, and the list is built again only when a moving vertex leaves that box or half of the vertices it was built
+        // for have retired (the tile of the rest is smaller, its list shorter) -- the steps shrink fast, so a few lists serve
+        // the whole descent (flat256 1024^3: 12.9 -> 11.6 ms).  Mixed joins at the root: a list per step, over the box of the
+        // vertices that are still moving (there the per-step list of the shrinking tile was the faster one).
+        // A LONG list means that the wave's vertices lie far apart (the order of the unique vertices is not coherent
+        // everywhere): such a wave used to run every object of the scene for all `steps` and set the kernel's duration on
+        // its own (VALU 5 % busy).  Its moving vertices are halved along the longest axis of their box, up to three times,
+        // each part with its own list; the parts are evaluated one after the other.  Retired lanes run along and are ignored.
+        // (Both for plain unions only: where groups have to be walked for every list, the extra lists cost more than they
+        // saved -- grouped256 10.0 -> 10.6 ms, smooth256 512^3 13.6 -> 17.1 -- so those scenes keep the plain loop below.)
+        const bool reuse = (s.flags & 2) != 0;
+        const int long_list = s.n_stack_steps / 4 > 48 ? s.n_stack_steps / 4 : 48;
+        const int lane = (int)(threadIdx.x & (DCSG_WAVE - 1u));
+        int n_list = 0, built_for = 0;  // built_for: the number of moving vertices the list was built for; 0 = not for all of them
+        DcsgTileReach reach = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (!reuse) {
             for (int k = 0; k < steps; k++) {
                 if (__builtin_amdgcn_ballot_w64(!d.done) == 0ull) break;
                 const float x = d.x, y = d.y, z = d.z;
                 DcsgTileReach unused;
-                int n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, 0.0f, unused);
+                n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, 0.0f, unused);
                 float sd, nx, ny, nz;
                 dcsg_stencil<4>(s, x, y, z, true, true, sd, nx, ny, nz, list, n_list);
                 float m = -sd;
                 dcsg_descent_advance(d, x + m * nx, y + m * ny, z + m * nz, k, steps);
             }
+        }
+        for (int k = 0; reuse && k < steps; k++) {
+            const unsigned long long moving = __builtin_amdgcn_ballot_w64(!d.done);
+            if (moving == 0ull) break;
+            const float x = d.x, y = d.y, z = d.z;
+            float qx = x, qy = y, qz = z;  // the step's result F(p) per lane
+            unsigned long long pending = moving;
+            while (pending != 0ull) {  // wave-uniform: one round per part (one round for almost every wave)
+                bool in_part = ((pending >> lane) & 1ull) != 0ull;
+                bool build = true;
+                float grow = 0.0f;
+                if (pending == moving) {
+                    const bool outside = in_part && !(__builtin_fabsf(x - reach.cx) <= reach.ax && __builtin_fabsf(y - reach.cy) <= reach.ay &&
+                                                      __builtin_fabsf(z - reach.cz) <= reach.az);
+                    build = built_for == 0 || 2 * __popcll(moving) <= built_for || __builtin_amdgcn_ballot_w64(outside) != 0ull;
+                    grow = 0.05f;
+                }
+                for (int halvings = 0;; halvings++) {
+                    if (build) {
+                        n_list = dcsg_build_active_list(s, in_part, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, grow, reach);
+                        built_for = (pending == moving && halvings == 0) ? __popcll(moving) : 0;
+                    }
+                    if (n_list <= long_list || halvings == 3) break;
+                    // the half (along the longest axis of the part's box) that holds the part's first vertex
+                    const float c = reach.ax >= reach.ay && reach.ax >= reach.az ? x - reach.cx : (reach.ay >= reach.az ? y - reach.cy : z - reach.cz);
+                    const unsigned long long part = __builtin_amdgcn_ballot_w64(in_part);
+                    const unsigned long long low = __builtin_amdgcn_ballot_w64(in_part && c <= 0.0f);
+                    const unsigned long long keep = ((low >> __builtin_ctzll(part)) & 1ull) ? low : part & ~low;
+                    if (keep == part) break;  // all on one side (coincident vertices): no further
+                    in_part = ((keep >> lane) & 1ull) != 0ull;
+                    build = true;
+                    grow = 0.0f;
+                }
+                float psd, pnx, pny, pnz;
+                dcsg_stencil<4>(s, x, y, z, true, true, psd, pnx, pny, pnz, list, n_list);
+                if (in_part) {
+                    const float m = -psd;
+                    qx = x + m * pnx, qy = y + m * pny, qz = z + m * pnz;
+                }
+                pending &= ~__builtin_amdgcn_ballot_w64(in_part);
+            }
+            dcsg_descent_advance(d, qx, qy, qz, k, steps);
         }
         if (valid) {
             verts[(size_t)i * 3 + 0] = d.x;
