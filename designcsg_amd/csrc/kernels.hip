@@ -2788,26 +2788,17 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
         // everywhere): such a wave used to run every object of the scene for all `steps` and set the kernel's duration on
         // its own (VALU 5 % busy).  Its moving vertices are halved along the longest axis of their box, up to three times,
         // each part with its own list; the parts are evaluated one after the other.  Retired lanes run along and are ignored.
-        // (Both for plain unions only: where groups have to be walked for every list, the extra lists cost more than they
-        // saved -- grouped256 10.0 -> 10.6 ms, smooth256 512^3 13.6 -> 17.1 -- so those scenes keep the plain loop below.)
+        // (Mixed scenes, where every list costs a walk of all groups: a longer threshold, and no more halving for a tile once a
+        // half's list came out barely shorter than the whole's -- smooth256 1024^3 19.9 -> 16.0 ms, 512^3 13.7 -> 12.6;
+        // grouped256 10.1 -> 10.3, 11.7 -> 9.4.)
         const bool reuse = (s.flags & 2) != 0;
-        const int long_list = s.n_stack_steps / 4 > 48 ? s.n_stack_steps / 4 : 48;
+        const int long_list = reuse ? (s.n_stack_steps / 4 > 48 ? s.n_stack_steps / 4 : 48) : (s.n_stack_steps / 2 > 96 ? s.n_stack_steps / 2 : 96);
         const int lane = (int)(threadIdx.x & (DCSG_WAVE - 1u));
         int n_list = 0, built_for = 0;  // built_for: the number of moving vertices the list was built for; 0 = not for all of them
         DcsgTileReach reach = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        if (!reuse) {
-            for (int k = 0; k < steps; k++) {
-                if (__builtin_amdgcn_ballot_w64(!d.done) == 0ull) break;
-                const float x = d.x, y = d.y, z = d.z;
-                DcsgTileReach unused;
-                n_list = dcsg_build_active_list(s, !d.done, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, 0.0f, unused);
-                float sd, nx, ny, nz;
-                dcsg_stencil<4>(s, x, y, z, true, true, sd, nx, ny, nz, list, n_list);
-                float m = -sd;
-                dcsg_descent_advance(d, x + m * nx, y + m * ny, z + m * nz, k, steps);
-            }
-        }
-        for (int k = 0; reuse && k < steps; k++) {
+        bool halving_pays = true;  // until a half's list comes out barely shorter than the whole's (a densely populated tile)
+        int parent_list = 0;
+        for (int k = 0; k < steps; k++) {
             const unsigned long long moving = __builtin_amdgcn_ballot_w64(!d.done);
             if (moving == 0ull) break;
             const float x = d.x, y = d.y, z = d.z;
@@ -2817,7 +2808,7 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
                 bool in_part = ((pending >> lane) & 1ull) != 0ull;
                 bool build = true;
                 float grow = 0.0f;
-                if (pending == moving) {
+                if (pending == moving && reuse) {
                     const bool outside = in_part && !(__builtin_fabsf(x - reach.cx) <= reach.ax && __builtin_fabsf(y - reach.cy) <= reach.ay &&
                                                       __builtin_fabsf(z - reach.cz) <= reach.az);
                     build = built_for == 0 || 2 * __popcll(moving) <= built_for || __builtin_amdgcn_ballot_w64(outside) != 0ull;
@@ -2828,7 +2819,10 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
                         n_list = dcsg_build_active_list(s, in_part, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, grow, reach);
                         built_for = (pending == moving && halvings == 0) ? __popcll(moving) : 0;
                     }
-                    if (n_list <= long_list || halvings == 3) break;
+                    // mixed scenes (a list costs a walk of every group): a half whose list is barely shorter ends the halving for this tile
+                    if (!reuse && halvings > 0 && 4 * n_list > 3 * parent_list) halving_pays = false;
+                    if (n_list <= long_list || halvings == 3 || !halving_pays) break;
+                    parent_list = n_list;
                     // the half (along the longest axis of the part's box) that holds the part's first vertex
                     const float c = reach.ax >= reach.ay && reach.ax >= reach.az ? x - reach.cx : (reach.ay >= reach.az ? y - reach.cy : z - reach.cz);
                     const unsigned long long part = __builtin_amdgcn_ballot_w64(in_part);
