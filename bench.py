@@ -93,6 +93,42 @@ def cpu_baseline(scene_dir, center, diameter, res, budget_s=15.0):
                       "%d points, %.1f s)" % (planes, n1, planes / n1, n1, pts, dt)}
 
 
+def reference_kernel_same_box(scene, scene_dir, center, diameter, res):
+    """The REFERENCE's own kernel k2 (k2.cl + the scene's brush text, compiled for gfx950 by `make -C oracle ref-k2`
+    with the reference's build options) on this box's GPU, launched as Evaluator.cpp:149-152,195-198 launches it:
+    one batch of MAX_EVAL_POINTS = 16 777 216 lattice points, one SDF launch and one normal launch, LOCAL SIZE 1.
+    Part of the cpu_baseline leg (checker code, oracle/ref_k2.py); None where the code objects were not built."""
+    from oracle import ref_k2 as R
+    if not os.path.exists(R.hsaco_path(scene, "default")):
+        return None
+    import numpy as np
+    n1 = res + 1
+    n = min(R.MAX_EVAL_POINTS, n1 ** 3)
+    idx = np.arange(n, dtype=np.int64)
+    d, w = np.float32(diameter), np.float32(res)
+    axis = lambda c, i: (np.float32(c) - d * np.float32(0.5)) + (d * i.astype(np.float32)) / w     # ISV.hpp:103-109
+    pts = np.stack([axis(center[0], idx % n1), axis(center[1], (idx // n1) % n1), axis(center[2], idx // (n1 * n1))], -1)
+    k = R.RefK2(scene_dir, "default", scene_name=scene, max_points=n)
+    try:
+        k.eval_sdf_at_points(pts[:1 << 16])            # untimed: first launch of the module
+        t0 = time.perf_counter()
+        k.eval_sdf_at_points(pts)
+        ms_sdf = k.last_kernel_ms
+        k.eval_normal_at_points(pts)
+        ms_nrm = k.last_kernel_ms
+        wall = time.perf_counter() - t0
+    finally:
+        k.close()
+    vox = n * (res ** 3 / n1 ** 3)
+    return {"value": round(vox / ((ms_sdf + ms_nrm) * 1e-3) / 1e6, 2), "unit": "Mvoxels/s", "kind": "reference",
+            "kernel_ms": {"sdf": round(ms_sdf, 3), "normal": round(ms_nrm, 3)},
+            "with_blocking_transfers_Mvoxels_per_s": round(vox / wall / 1e6, 2),
+            "sample": "reference kernel k2 (oracle/_ref/k2_%s_default.hsaco: the reference's text and build options, gfx950) on "
+                      "the first %d points of the %d^3 lattice, one SDF + one normal launch at local size 1 "
+                      "(Evaluator.cpp:149-152,195-198); value = kernel time only (HIP events), the second figure includes "
+                      "the reference's three blocking transfers per call" % (scene, n, n1)}
+
+
 # kernel that a fused SDF+normal sweep launches, by interpreter variant (dcsg_api.cpp: sweep_device); the SDF-only
 # sweep launches the `_d` instantiation of the same kernel
 KERNEL_VARIANT = {0: "dcsg_sweep_f", 1: "dcsg_sweep_s4_f", 2: "dcsg_sweep_s8_f", 3: "dcsg_sweep_sp_f", 4: "dcsg_sweep_c4_f"}
@@ -588,6 +624,9 @@ def main():
             out["export_wall_clock"] = export_wall_clock()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_dir, center, diameter, res)
+            ref = reference_kernel_same_box(scene, scene_dir, center, diameter, res)
+            if ref:
+                out["cpu_baseline"]["reference_kernel_same_box"] = ref
         print(json.dumps(out))
     ev.close()
     if world > 1:
