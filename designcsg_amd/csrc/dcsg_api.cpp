@@ -11,11 +11,13 @@
 #include <sys/vfs.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -46,6 +48,7 @@ struct Kernels {
     hipFunction_t sweep_nodes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // node-wise sweep per variant
     hipFunction_t dd_insert = nullptr, dd_resolve = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
     hipFunction_t rt_mark = nullptr, rt_count = nullptr, rt_emit = nullptr;  // opt-in retopologize
+    hipFunction_t cells_mark = nullptr, cells_collect = nullptr, cells_build = nullptr, project_cells = nullptr;  // cell lists of many-object scenes (built-in module)
 };
 
 double now_s()
@@ -68,11 +71,25 @@ struct dcsg_ctx {
     // (need_rest).  After a cold build of the export part the rest is compiled by a background host thread (comgr only,
     // no HIP call) while the caller already exports.
     hipModule_t scene_mod_rest = nullptr;
-    std::thread rest_thread;
+    // The background build OWNS what it reads and writes (its inputs are copies, its outputs its own members): nothing of
+    // the context is touched from the thread, so an early return of the call that started it -- or a later call that
+    // rewrites the context's rest_* fields -- cannot race with it.  The context reads `hsaco / log / ok` only after join().
+    struct RestJob {
+        std::string cl, extra;
+        bool relaxed = false, spec = false;
+        JitEnv env;                 // the JIT's environment switches as the starting call saw them (no getenv in the thread)
+        std::string hsaco, log;
+        bool ok = false;
+        std::thread thread;
+        ~RestJob()
+        {
+            if (thread.joinable()) thread.join();
+        }
+    };
+    std::unique_ptr<RestJob> rest_job;
     bool rest_wanted = false;   // the loaded scene has a rest part that is not loaded yet
-    bool rest_thread_ok = false;
     int rest_kind = 0;
-    std::string rest_cl, rest_extra, rest_hsaco, rest_log;
+    std::string rest_cl, rest_extra;   // what the rest part of the LOADED scene is built from (host thread only)
     bool rest_relaxed = false, rest_spec = false;
     DevBuf d_node_mask;                 // node-wise sweep: which nodes of the sweep level hold lattice values
     hipModule_t preview_mod = nullptr;  // scene.cl as given + kernels, built on the first dcsg_render_preview of a scene
@@ -92,6 +109,12 @@ struct dcsg_ctx {
     std::vector<uint8_t> tri_table;
     DevBuf d_blob, d_ad, d_tri_table, d_pts, d_out, d_nodes[2], d_info, d_block_sums, d_small, d_tris, d_lat_sdf,
         d_lat_nrm, d_dd_table, d_dd_rep, d_dd_slot, d_dd_compact, d_rt_keep, d_rt_out;
+    // cell lists (kernels.hip "Cell lists"): built on the first projection of a many-object scene, kept until the next scene
+    DevBuf d_cells, d_cell_entries, d_cell_want, d_cell_words, d_cell_work;
+    DcsgCellGrid cell_grid = {};
+    bool cells_valid = false;
+    double cells_built_ms = 0;  // host-side time spent building cells of the loaded scene so far (launch to completion)
+    uint64_t cell_entries = 0, cells_built = 0;
     uint64_t n_tris = 0;
     uint64_t last_unique_vertices = 0;  // distinct positions projected by the last dcsg_project_triangles
     void* h_pinned = nullptr;  // host staging for triangle downloads
@@ -214,6 +237,10 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind, int part = 
         HIPCHK(c, hipModuleGetFunction(&k.sweep_nodes[4], mod, "dcsg_sweep_nodes_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.bbox[4], mod, "dcsg_bbox_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.project[4], mod, "dcsg_project_c4"));
+        HIPCHK(c, hipModuleGetFunction(&k.cells_mark, mod, "dcsg_cells_mark"));
+        HIPCHK(c, hipModuleGetFunction(&k.cells_collect, mod, "dcsg_cells_collect"));
+        HIPCHK(c, hipModuleGetFunction(&k.cells_build, mod, "dcsg_cells_build"));
+        HIPCHK(c, hipModuleGetFunction(&k.project_cells, mod, "dcsg_project_cells"));
         k.eval_points[4] = k.eval_points[1];  // arbitrary points have no spatial coherence to exploit
     } else {
         HIPCHK(c, hipModuleGetFunction(part == 2 ? &k.set_ad_rest : &k.set_ad, mod, "dcsg_set_arbitrary_data"));
@@ -327,10 +354,28 @@ int need_scene(dcsg_ctx* c)
     return 0;
 }
 
-// Ends the background build of the rest part, if one is running (the result stays in c->rest_hsaco).
+// Starts the background build of a scene's rest part.  The caller has joined the previous job (join_rest_thread).
+void start_rest_job(dcsg_ctx* c, const ModulePlan& plan)
+{
+    c->rest_job.reset(new dcsg_ctx::RestJob());
+    dcsg_ctx::RestJob* job = c->rest_job.get();
+    job->cl = plan.cl;
+    job->extra = plan.extra;
+    job->relaxed = plan.relaxed;
+    job->spec = plan.specialise;
+    job->env = JitEnv::from_environment();  // read here, on the caller's thread
+    job->thread = std::thread([job] {
+        bool from_cache = false;
+        job->ok = jit_scene_module(job->cl, job->extra, job->hsaco, job->log, &from_cache, job->relaxed, job->spec, JIT_PART_REST, false,
+                                   &job->env);
+    });
+}
+
+// Ends the background build of the rest part, if one is running (its result stays in c->rest_job).  One comgr build at a
+// time per context: every path that starts a build or replaces the job calls this first.
 void join_rest_thread(dcsg_ctx* c)
 {
-    if (c->rest_thread.joinable()) c->rest_thread.join();
+    if (c->rest_job && c->rest_job->thread.joinable()) c->rest_job->thread.join();
 }
 
 // Makes the rest part of the scene module available: dense sweeps, point evaluation, T-junction repair, test kernels.
@@ -339,23 +384,32 @@ int need_rest(dcsg_ctx* c)
 {
     if (!c->jit || !c->rest_wanted) return 0;
     join_rest_thread(c);
-    if (c->rest_hsaco.empty() || !c->rest_thread_ok) {
+    std::string hsaco, log;
+    if (c->rest_job && c->rest_job->ok && !c->rest_job->hsaco.empty()) {
+        hsaco.swap(c->rest_job->hsaco);   // the background build of THIS scene (dcsg_load_scene replaces the job per scene)
+    } else {
         bool cached = false;
-        c->rest_log.clear();
-        if (!jit_scene_module(c->rest_cl, c->rest_extra, c->rest_hsaco, c->rest_log, &cached, c->rest_relaxed, c->rest_spec, JIT_PART_REST))
-            return fail(c, DCSG_ERR_BUILD, "Error when building evaluation program:\n" + c->rest_log);
+        if (!jit_scene_module(c->rest_cl, c->rest_extra, hsaco, log, &cached, c->rest_relaxed, c->rest_spec, JIT_PART_REST))
+            return fail(c, DCSG_ERR_BUILD, "Error when building evaluation program:\n" + log);
     }
+    c->rest_job.reset();
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipModuleLoadData(&c->scene_mod_rest, c->rest_hsaco.data()));
+    HIPCHK(c, hipModuleLoadData(&c->scene_mod_rest, hsaco.data()));
+    // any failure from here on unloads the module again: rest_wanted stays set and the next call starts over, without a
+    // second copy of the code object left behind
+    auto drop = [c](int rc) {
+        hipModuleUnload(c->scene_mod_rest);
+        c->scene_mod_rest = nullptr;
+        return rc;
+    };
     int r = load_kernels(c, c->scene_mod_rest, c->ks, c->rest_kind, 2);
-    if (r) return r;
+    if (r) return drop(r);
     void* adp = c->d_ad.p;
     void* args[] = {&adp};
-    if ((r = launch(c, c->ks.set_ad_rest, 1, 64, 0, c->stream, args))) return r;
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // other streams may launch this module's kernels next
+    if ((r = launch(c, c->ks.set_ad_rest, 1, 64, 0, c->stream, args))) return drop(r);
+    // other streams may launch this module's kernels next
+    if (hipError_t e = hipStreamSynchronize(c->stream)) return drop(fail(c, DCSG_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)));
     c->rest_wanted = false;
-    c->rest_hsaco.clear();
-    c->rest_hsaco.shrink_to_fit();
     return 0;
 }
 
@@ -447,8 +501,8 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     // (diagnostic switches are read per call, not cached: tests flip them inside one process; four lookups are well under a
     // microsecond of the five a launch costs the host)
     const bool no_rows = getenv("DCSG_NO_ROWS") != nullptr, no_multipass = getenv("DCSG_NO_MULTIPASS") != nullptr;
-    // read by the SDF + normal sweeps of per-scene code (dcsg_stencil_spec) and by the A/B forms (-DDCSG_SWEEP_FORMS)
-    if (c->variant < 4 && !no_rows && (d_nrm || (d_sdf && getenv("DCSG_SWEEP_FORM")))) {
+    // read by the SDF + normal sweeps of per-scene code (dcsg_stencil_spec)
+    if (c->variant < 4 && !no_rows && d_nrm) {
         // the answer depends on the lattice alone: remembered for the last one (a bench or a slab loop sweeps the same
         // lattice again and again, and 3 (res+1) volatile float operations are microseconds of host time per launch)
         if (!c->nz_valid || memcmp(&c->nz_lattice, &L, sizeof(L)) != 0) {
@@ -470,12 +524,6 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
         if (!c->nz_result) flags |= DCSG_SWEEP_NO_NEG_ZERO;
     }
     if (!no_multipass) flags |= DCSG_SWEEP_MULTIPASS;
-    {   // DCSG_SWEEP_FORM = run4 | merged (A/B builds with -DDCSG_SWEEP_FORMS only; the product has the plain form alone)
-        const char* form = getenv("DCSG_SWEEP_FORM");
-        const std::string f = form ? form : "plain";
-        if (f == "run4") flags |= DCSG_SWEEP_RUN4;
-        else if (f == "merged") flags |= DCSG_SWEEP_MERGED;
-    }
     // diagnostic: unused LDS per block, to hold fewer blocks on a CU (occupancy experiments, tools/ab_sweep.py)
     static const size_t lds_pad = getenv("DCSG_SWEEP_LDS_PAD") ? (size_t)atol(getenv("DCSG_SWEEP_LDS_PAD")) : 0;
     if (lds + lds_pad <= c->max_lds) lds += lds_pad;
@@ -499,6 +547,9 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
     if (time_it) {
         HIPCHK(c, hipEventRecord(t_ev1, s));
         c->have_sweep_time = true;
+    } else {
+        c->have_sweep_time = false;  // "the most recent sweep" was not timed: dcsg_last_sweep_ms says so instead of
+                                     // returning an older sweep's duration
     }
     return 0;
 }
@@ -605,7 +656,7 @@ void dcsg_destroy(dcsg_ctx* c)
     DevBuf* bufs[] = {&c->d_blob,  &c->d_ad,         &c->d_tri_table, &c->d_pts,  &c->d_out,     &c->d_nodes[0],
                       &c->d_nodes[1], &c->d_info,    &c->d_block_sums, &c->d_small, &c->d_tris, &c->d_lat_sdf,
                       &c->d_lat_nrm, &c->d_dd_table, &c->d_dd_rep, &c->d_dd_slot, &c->d_dd_compact, &c->d_node_mask,
-                      &c->d_rt_keep, &c->d_rt_out};
+                      &c->d_rt_keep, &c->d_rt_out, &c->d_cells, &c->d_cell_entries, &c->d_cell_want, &c->d_cell_words, &c->d_cell_work};
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     join_rest_thread(c);
@@ -722,6 +773,7 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
         c->k = &c->kb;
         c->jit = false;
         join_rest_thread(c);
+        c->rest_job.reset();
         c->rest_wanted = false;
     } else {
         std::string hsaco, log;
@@ -752,18 +804,12 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
         c->rest_extra = plan.extra;
         c->rest_relaxed = plan.relaxed;
         c->rest_spec = plan.specialise;
-        c->rest_hsaco.clear();
-        c->rest_log.clear();
-        c->rest_thread_ok = false;
+        c->rest_job.reset();  // joined above; a result of the previous scene is of no use
         if (!cached) {
             if (getenv("DCSG_JIT_SYNC")) {
                 sync_rest = true;
             } else {
-                c->rest_thread = std::thread([c] {
-                    bool from_cache = false;
-                    c->rest_thread_ok = jit_scene_module(c->rest_cl, c->rest_extra, c->rest_hsaco, c->rest_log, &from_cache, c->rest_relaxed,
-                                                         c->rest_spec, JIT_PART_REST);
-                });
+                start_rest_job(c, plan);
             }
         }
         build_blob(s, plan.null0);
@@ -800,6 +846,7 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
         // f == 4: culling is only ever chosen by the rule above
     }
     c->scene_loaded = true;
+    c->cells_valid = false;
     c->n_tris = 0;
     c->scene_cl_text = scene_cl ? scene_cl : "";
     if (c->preview_mod) {  // belongs to the previous scene
@@ -909,7 +956,8 @@ int dcsg_set_sweep_timing(dcsg_ctx* c, int on)
 int dcsg_last_sweep_ms(dcsg_ctx* c, double* ms)
 {
     if (!c || !ms) return DCSG_ERR_INVALID;
-    if (!c->have_sweep_time) return fail(c, DCSG_ERR_INVALID, "no sweep has been timed yet");
+    if (!c->have_sweep_time)
+        return fail(c, DCSG_ERR_INVALID, "the last sweep was not timed (dcsg_sweep_lattice_device records events only after dcsg_set_sweep_timing(ctx, 1))");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventSynchronize(c->sweep_ev[c->sweep_ev_next][1]));
     float t = 0;
@@ -1130,9 +1178,18 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
         unsigned* d_bs = (unsigned*)c->d_block_sums.p;
         unsigned long long* d_ls = d_lstats + 4 * level;
         {
+            // the eight corner normals of a block's nodes wait in 32 KiB of LDS behind the scene's area -- where a scene of
+            // more than a thousand objects leaves that room; otherwise the kernel samples per edge end (corner_off = -1)
+            size_t lds = (c->scene.lds_bytes() + 15) & ~(size_t)15;
+            const size_t corner_bytes = (size_t)8 * 4 * DCSG_BLOCK * sizeof(float);
+            int corner_off = -1;
+            if (lds + corner_bytes + 256 <= c->max_lds && !getenv("DCSG_CLASSIFY_NO_LDS_NORMALS")) {
+                corner_off = (int)lds;
+                lds += corner_bytes;
+            }
             void* args[] = {(void*)&blob, &nv, &P, (void*)&d_nodes, &n_nodes, (void*)&d_sdf, (void*)&d_normals,
-                            (void*)&d_table, (void*)&d_info, (void*)&d_bs, (void*)&d_ls};
-            if ((r = launch(c, c->k->classify, n_blocks, DCSG_BLOCK, c->scene.lds_bytes(), s, args))) return r;
+                            (void*)&d_table, (void*)&d_info, (void*)&d_bs, (void*)&d_ls, &corner_off};
+            if ((r = launch(c, c->k->classify, n_blocks, DCSG_BLOCK, lds, s, args))) return r;
         }
         {
             void* args[] = {(void*)&d_bs, &n_blocks, (void*)&d_totals};
@@ -1188,12 +1245,182 @@ int dcsg_mesh_lattice_device(dcsg_ctx* c, const float center[3], float diameter,
                      nullptr);
 }
 
+}  // extern "C"
+
+namespace {
+// The cube the cell lists cover: every object's bounding sphere (its brush lives in [-0.5, 0.5]^3 of the local frame,
+// whose axes are the reciprocals of the stored vectors, scenecompiler.py:538-541), a twentieth more.  Vertices outside
+// it are still projected correctly (the pseudo-cell of the whole program), only slowly.
+DcsgCellGrid cell_grid_for(const Scene& sc, int g)
+{
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    bool any = false;
+    for (int o = 0; o < sc.n_objects; o++) {
+        if (sc.shape[o] <= 1) continue;  // null / void brushes have no surface
+        double r2 = 0;
+        const float* ax[3] = {&sc.right[3 * o], &sc.up[3 * o], &sc.fwd[3 * o]};
+        for (auto a : ax) {
+            const double q = (double)a[0] * a[0] + (double)a[1] * a[1] + (double)a[2] * a[2];
+            r2 += q > 0 ? 0.25 / q : 1e12;  // half an axis: 0.5 / |reciprocal vector|
+        }
+        const float rad = (float)std::sqrt(r2);
+        if (!(rad < 1e5f)) continue;
+        for (int k = 0; k < 3; k++) {
+            const float a = sc.pos[3 * o + k] - rad, b = sc.pos[3 * o + k] + rad;
+            lo[k] = any ? std::min(lo[k], a) : a;
+            hi[k] = any ? std::max(hi[k], b) : b;
+        }
+        any = true;
+    }
+    float side = 1.0f;
+    for (int k = 0; k < 3; k++) side = std::max(side, hi[k] - lo[k]);
+    side *= 1.05f;
+    DcsgCellGrid G;
+    G.g = g;
+    G.cell = side / (float)g;
+    G.inv_cell = (float)g / side;
+    G.x0 = 0.5f * (lo[0] + hi[0]) - 0.5f * side;
+    G.y0 = 0.5f * (lo[1] + hi[1]) - 0.5f * side;
+    G.z0 = 0.5f * (lo[2] + hi[2]) - 0.5f * side;
+    return G;
+}
+
+// Device words of the cell-list machinery (their own buffer: the entry counter lives as long as the scene's cells do,
+// and the exports clear d_small): 0 entry counter, 1 vertex queue, 2 parked count, 3 cells built
+unsigned* cells_word(dcsg_ctx* c, int k) { return (unsigned*)c->d_cell_words.p + k; }
+
+// Grid and empty tables for the loaded scene (no cell built yet).
+int ensure_cell_grid(dcsg_ctx* c, hipStream_t s)
+{
+    if (c->cells_valid) return 0;
+    const char* eg = getenv("DCSG_CELLS");
+    int g = eg ? atoi(eg) : 64;
+    g = (g < 4 ? 4 : (g > 256 ? 256 : g)) & ~3;  // a coarse cell is 4 x 4 x 4 fine ones
+    c->cell_grid = cell_grid_for(c->scene, g);
+    const uint64_t n_cells = (uint64_t)g * g * g, n_coarse = n_cells / 64, n_all = n_cells + 1 + n_coarse;
+    int r;
+    if ((r = ensure(c, c->d_cells, n_all * sizeof(uint32_t) * 2))) return r;
+    if ((r = ensure(c, c->d_cell_want, n_all))) return r;
+    if ((r = ensure(c, c->d_cell_words, 256))) return r;
+    if ((r = ensure(c, c->d_cell_work, (n_all + 1) * sizeof(uint32_t)))) return r;
+    // entries are handed out in chunks of 512 per wave of the build (kernels.hip DCSG_CELL_CHUNK): room for the lists and for
+    // a part-used chunk per wave of a launch
+    const uint64_t capacity = std::max<uint64_t>(n_cells * 8, 4u << 20) + (uint64_t)c->n_cu * 12 * 4 * 512 + (uint64_t)c->scene.n_stack_prog;
+    if ((r = ensure(c, c->d_cell_entries, capacity * sizeof(uint32_t)))) return r;
+    HIPCHK(c, hipMemsetAsync(c->d_cells.p, 0xff, n_all * sizeof(uint32_t) * 2, s));  // DCSG_CELL_NOT_BUILT
+    HIPCHK(c, hipMemsetAsync(c->d_cell_want.p, 0, n_cells, s));
+    // wanted from the start: the pseudo-cell of the whole program and every coarse cell
+    HIPCHK(c, hipMemsetAsync((char*)c->d_cell_want.p + n_cells, 1, 1 + n_coarse, s));
+    HIPCHK(c, hipMemsetAsync(cells_word(c, 0), 0, 4 * sizeof(unsigned), s));
+    c->cell_entries = 0;
+    c->cells_built = 0;
+    c->cells_built_ms = 0;
+    c->cells_valid = true;
+    return 0;
+}
+
+// Builds every wanted cell.  The entry buffer grows when the counter says it was too small (the cells that did not fit stay
+// wanted and are built by the next launch).
+int build_wanted_cells(dcsg_ctx* c, hipStream_t s)
+{
+    const uint64_t n_fine = (uint64_t)c->cell_grid.g * c->cell_grid.g * c->cell_grid.g, n_cells = n_fine + n_fine / 64;  // + the pseudo-cell below
+    const double t0 = now_s();
+    int r;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        const uint64_t capacity = c->d_cell_entries.cap / sizeof(uint32_t);
+        const void* blob = c->d_blob.p;
+        int nv = c->scene.blob_vec4();
+        void* cells = c->d_cells.p;
+        void* entries = c->d_cell_entries.p;
+        void* want = c->d_cell_want.p;
+        unsigned* counter = cells_word(c, 0);
+        unsigned cap = (unsigned)std::min<uint64_t>(capacity, 0xfffffff0ull);
+        // the wanted cells as a list (they are clustered), then one wave per list entry
+        void* work = c->d_cell_work.p;
+        HIPCHK(c, hipMemsetAsync(work, 0, sizeof(unsigned), s));
+        {
+            unsigned np1 = (unsigned)(n_cells + 1);
+            void* cargs[] = {&want, &np1, &work};
+            if ((r = launch(c, c->kb.cells_collect, (unsigned)std::min<uint64_t>((n_cells + 256) / 256, (uint64_t)c->n_cu * 8), DCSG_BLOCK, 0, s, cargs)))
+                return r;
+        }
+        void* args[] = {(void*)&blob, &nv, (void*)&c->cell_grid, &cells, &entries, (void*)&counter, &cap, &want, &work};
+        const unsigned blocks = (unsigned)std::min<uint64_t>((n_cells + 4) / 4, (uint64_t)c->n_cu * 12);
+        if ((r = launch(c, c->kb.cells_build, blocks, DCSG_BLOCK, c->scene.lds_bytes(), s, args))) return r;
+        unsigned words[4] = {0, 0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(words, counter, sizeof(words), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const unsigned used = words[0];
+        c->cells_built = words[3];
+        if (used <= cap) {
+            c->cell_entries = used;
+            c->cells_built_ms += (now_s() - t0) * 1e3;
+            return 0;
+        }
+        // too small: the counter ran past the capacity.  Entries written so far stay where they are (cells point at them);
+        // the counter goes back to the last entry that was written and the buffer grows, keeping its contents
+        if (cap >= 0xfffffff0u) return fail(c, DCSG_ERR_INVALID, "cell lists do not fit 2^32 entries");
+        const uint64_t want_cap = (uint64_t)used * 2 + 4096;
+        // the cells that fitted were appended below `cap`; everything in [0, cap) is live or a hole
+        if ((r = ensure(c, c->d_cell_entries, want_cap * sizeof(uint32_t), true, (size_t)cap * sizeof(uint32_t)))) return r;
+        HIPCHK(c, hipMemcpyAsync(counter, &cap, sizeof(unsigned), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    return fail(c, DCSG_ERR_HIP, "cell lists: the entry count kept growing");
+}
+
+// Projection through the cell lists: many-object scenes of built-in brushes (variant 4).  The cells the vertices start in
+// (and their neighbours) are built first, together with whatever earlier projections of this scene asked for; a vertex that
+// strays into a cell nobody built reads the coarse cell around it and leaves a request.  One launch, no read-back besides
+// the build's entry counter.
+int project_cells(dcsg_ctx* c, float* d_xyz, unsigned n, int steps, hipStream_t s)
+{
+    int r = ensure_cell_grid(c, s);
+    if (r) return r;
+    const void* blob = c->d_blob.p;
+    int nv = c->scene.blob_vec4();
+    void* want = c->d_cell_want.p;
+    {
+        void* args[] = {(void*)&d_xyz, &n, (void*)&c->cell_grid, &want};
+        if ((r = launch(c, c->kb.cells_mark, sweep_grid(c, (n + DCSG_BLOCK - 1) / DCSG_BLOCK), DCSG_BLOCK, 0, s, args))) return r;
+    }
+    if ((r = build_wanted_cells(c, s))) return r;
+    const int refill_env = getenv("DCSG_PROJECT_REFILL") ? atoi(getenv("DCSG_PROJECT_REFILL")) : 16;
+    int refill_at = refill_env < 1 ? 1 : (refill_env > 64 ? 64 : refill_env);
+    const int per_cu = getenv("DCSG_PROJECT_BLOCKS_PER_CU") ? atoi(getenv("DCSG_PROJECT_BLOCKS_PER_CU")) : 4;
+    unsigned* queue = cells_word(c, 1);
+    HIPCHK(c, hipMemsetAsync(queue, 0, sizeof(unsigned), s));
+    const void* cells = c->d_cells.p;
+    const void* entries = c->d_cell_entries.p;
+    void* args[] = {(void*)&blob, &nv, (void*)&d_xyz, &n, &steps, (void*)&c->cell_grid, (void*)&cells, (void*)&entries, (void*)&queue,
+                    &refill_at, &want};
+    // persistent: as many blocks as stay resident (4 waves per SIMD), never more than there are 256-vertex groups
+    unsigned blocks = (unsigned)c->n_cu * (unsigned)(per_cu < 1 ? 1 : per_cu);
+    const unsigned groups = (n + DCSG_BLOCK - 1) / DCSG_BLOCK;
+    if (blocks > groups) blocks = groups;
+    return launch(c, c->kb.project_cells, blocks, DCSG_BLOCK, c->scene.lds_bytes(), s, args);
+}
+}  // namespace
+
+extern "C" {
+
+int dcsg_debug_cells(const dcsg_ctx* c, int* grid, uint64_t* cells_built, uint64_t* entries, double* build_ms)
+{
+    if (!c) return DCSG_ERR_INVALID;
+    if (grid) *grid = c->cells_valid ? c->cell_grid.g : 0;
+    if (cells_built) *cells_built = c->cells_built;
+    if (entries) *entries = c->cell_entries;
+    if (build_ms) *build_ms = c->cells_built_ms;
+    return 0;
+}
+
 int dcsg_project_vertices_device(dcsg_ctx* c, float* d_xyz, size_t n_vertices, int steps, void* stream)
 {
     int r = need_scene(c);
     if (r) return r;
     if (steps <= 0 || n_vertices == 0) return 0;
     if (n_vertices > 0xffffff00ull) return fail(c, DCSG_ERR_INVALID, "too many vertices for one launch");
+    if (c->variant == 4 && !getenv("DCSG_PROJECT_WAVE_LISTS")) return project_cells(c, d_xyz, (unsigned)n_vertices, steps, (hipStream_t)stream);
     const void* blob = c->d_blob.p;
     int nv = c->scene.blob_vec4();
     unsigned n = (unsigned)n_vertices;
@@ -1514,9 +1741,11 @@ struct Mapping {
     size_t map_len = 0;
 };
 // File systems on which a successful fallocate(2) means the blocks exist (unwritten extents / resident pages), so that
-// a store into the mapping cannot meet ENOSPC and kill the process with SIGBUS: ext2/3/4, XFS, tmpfs, and overlayfs
-// (which forwards fallocate to such an upper layer on the boxes this runs on).  Anything else -- NFS, FUSE, COW file
-// systems -- takes the pwrite path, where a full disk is an error return.  DCSG_WRITER_MMAP=1 forces the mapping.
+// a store into the mapping cannot meet ENOSPC and kill the process with SIGBUS: ext2/3/4, XFS, tmpfs.  overlayfs
+// forwards fallocate to its upper layer, which may be anything: there the reservation is VERIFIED -- the blocks the file
+// now occupies (st_blocks, the upper inode's) must cover its length -- before the mapping is chosen.  Anything else -- NFS,
+// FUSE, COW file systems, an overlay whose upper layer did not allocate -- takes the pwrite path, where a full disk is an
+// error return.  DCSG_WRITER_MMAP=1 forces the mapping.
 bool fs_honours_fallocate(int fd)
 {
     if (const char* e = getenv("DCSG_WRITER_MMAP")) return atoi(e) != 0;
@@ -1526,8 +1755,11 @@ bool fs_honours_fallocate(int fd)
     case 0xEF53ul:      // ext2 / ext3 / ext4
     case 0x58465342ul:  // XFS
     case 0x01021994ul:  // tmpfs
-    case 0x794c7630ul:  // overlayfs
         return true;
+    case 0x794c7630ul: {  // overlayfs: only with the allocation in evidence
+        struct stat st;
+        return fstat(fd, &st) == 0 && st.st_size > 0 && (uint64_t)st.st_blocks * 512u >= (uint64_t)st.st_size;
+    }
     default:
         return false;
     }
@@ -1837,6 +2069,54 @@ int dcsg_debug_normal_device(dcsg_ctx* c, const float* d_in, size_t n, float dy,
         if (int rr = need_rest(c)) return rr;
     hipFunction_t f = (c->scene_loaded && c->jit) ? c->ks.test_normal : c->kb.test_normal;
     return launch(c, f, (unsigned)c->n_cu * 16u, DCSG_BLOCK, 0, (hipStream_t)stream, args);
+}
+
+// Diagnostic, no device needed (thread-sanitizer harness, tests/test_host_threads.py): the host-side sequence of a cold
+// dcsg_load_scene -- export part compiled on this thread, rest part handed to the background job -- on a context that never
+// touches HIP.  *slot holds that context between calls (NULL: a new one).  mode 0: wait for the background build and report
+// it; mode 1: return at once with the build still running, as an early error return of dcsg_load_scene would (the next
+// call on the slot, or mode 2, has to cope); mode 2: destroy the slot's context (joins).  Returns 0, or DCSG_ERR_BUILD with
+// the compiler's log in log_out.
+int dcsg_debug_background_build(void** slot, const char* scene_txt, const char* bp_txt, const char* scene_cl, int mode, char* log_out,
+                                size_t log_cap)
+{
+    if (!slot) return DCSG_ERR_INVALID;
+    dcsg_ctx* c = (dcsg_ctx*)*slot;
+    auto say = [&](const std::string& m) {
+        if (log_out && log_cap) {
+            strncpy(log_out, m.c_str(), log_cap - 1);
+            log_out[log_cap - 1] = '\0';
+        }
+    };
+    if (mode == 2) {
+        delete c;  // ~RestJob joins
+        *slot = nullptr;
+        return 0;
+    }
+    if (!c) *slot = c = new dcsg_ctx();
+    Scene s;
+    std::string err, hsaco, log;
+    ModulePlan plan;
+    if (!parse_scene(scene_txt, bp_txt, s, err) || !plan_scene_module(s, scene_cl, plan, err)) {
+        say(err);
+        return DCSG_ERR_INVALID;
+    }
+    if (!plan.needs_jit) return 0;
+    join_rest_thread(c);  // what every path of dcsg_load_scene does before it touches the job
+    bool cached = false;
+    if (!jit_scene_module(plan.cl, plan.extra, hsaco, log, &cached, plan.relaxed, plan.specialise, JIT_PART_EXPORT)) {
+        say(log);
+        return DCSG_ERR_BUILD;
+    }
+    c->rest_job.reset();
+    start_rest_job(c, plan);
+    if (mode == 1) return 0;
+    join_rest_thread(c);
+    if (!c->rest_job->ok) {
+        say(c->rest_job->log);
+        return DCSG_ERR_BUILD;
+    }
+    return 0;
 }
 
 int dcsg_jit_prebuild_scene(const char* scene_txt, const char* bp_txt, const char* scene_cl, char* log_out, size_t log_cap,

@@ -6,16 +6,11 @@
 #define DCSG_BLOCK 256
 #define DCSG_WAVE 64
 #define DCSG_MAX_SLOTS 64  /* STACK_MEMORY_PER_PIXEL, Evaluator.cpp:7 */
-/* dcsg_sweep* `flags`: bit 0 = the lattice holds no -0.0 coordinate (checked by the host), so a sweep may share the
- * unperturbed stencil coordinates between points without looking (A/B forms of kernels.hip: dcsg_run4, dcsg_stencil_spec_merged) */
+/* dcsg_sweep* `flags`: bit 0 = the lattice holds no -0.0 coordinate (checked by the host), so a sweep of per-scene code
+ * may share the unperturbed stencil coordinates between the seven points without looking (dcsg_stencil_spec) */
 #define DCSG_SWEEP_NO_NEG_ZERO 1u
 /* bit 1 = the stack interpreters may serve several 64-point passes with one interpretation of the program */
 #define DCSG_SWEEP_MULTIPASS 2u
-/* bits 2, 3: which form the dense sweep of a store-bound scene takes (standard brushes, <= 4 object evaluations): four
- * points per lane (dcsg_run4), or one point per lane with one merged guard per point (dcsg_stencil_spec_merged); neither:
- * one point per lane, every square root with its own guard */
-#define DCSG_SWEEP_RUN4 4u
-#define DCSG_SWEEP_MERGED 8u
 
 struct DcsgLattice {  // ISV3D64 geometry, ISV.hpp:91-109
     float base[3];    // center - 0.5f*diameters   (ISV.hpp:104)
@@ -51,6 +46,15 @@ struct DcsgRetopo {  // T-junction repair in the spirit of cms::retopologize (me
     float grid_points;   // (float)((1 << gridLevel) + 1)
     int points_along_edge;  // 1 << (gridLevel - minimumOctreeLevel), <= 32
     float join_distance2;   // joinDistance^2, joinDistance = 0.25 * min_k(2 hd_k / grid_points) (mesh.hpp:445)
+};
+
+// Cell lists of many-object scenes (kernels.hip, "Cell lists"): a cube of g^3 cells of side `cell` with its low corner at
+// (x0, y0, z0); cells[c] = {first entry, entry count} of cell c = (iz * g + iy) * g + ix, cells[g^3] = the whole program
+// (points outside the cube).
+struct DcsgCellGrid {
+    float x0, y0, z0;
+    float cell, inv_cell;
+    int g;
 };
 
 struct DcsgCamera {  // kernel k1's campos / right / up / forward buffers (k1.cl:481-486)

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 #include <vector>
 
@@ -73,9 +74,9 @@ static std::vector<std::string> comgr_candidates()
     c.push_back("libamd_comgr.so.3");
     return c;
 }
-static std::string comgr_identity()
+static std::string comgr_identity(const std::vector<std::string>& candidates)
 {
-    for (auto& c : comgr_candidates()) {
+    for (auto& c : candidates) {
         struct stat st;
         if (stat(c.c_str(), &st) == 0)
             return c + ":" + std::to_string((long long)st.st_size);
@@ -83,13 +84,20 @@ static std::string comgr_identity()
     return "unknown";
 }
 
-static ComgrApi& comgr()
+// Loaded once per process (the first caller's candidate list decides), under a lock: contexts on different host threads
+// -- dcsg_export_multi, a background build next to another context's load -- may get here together.
+static ComgrApi& comgr(const std::vector<std::string>* candidates = nullptr)
 {
     static ComgrApi api;
-    if (api.handle || !api.error.empty()) return api;
-    std::vector<std::string> candidates = comgr_candidates();
-    for (auto& c : candidates) {
+    static std::mutex once;
+    std::lock_guard<std::mutex> lock(once);
+    if (api.handle || !api.error.empty() || !candidates) return api;
+    for (auto& c : *candidates) {
+#if defined(__SANITIZE_THREAD__) || defined(__SANITIZE_ADDRESS__)
+        api.handle = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);  // the sanitizer runtimes refuse RTLD_DEEPBIND (tools/sanitize_host.sh)
+#else
         api.handle = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+#endif
         if (api.handle) break;
         api.error += std::string(dlerror()) + "\n";
     }
@@ -240,12 +248,13 @@ static std::string collect(amd_comgr_data_set_t set, amd_comgr_data_kind_t kind)
 static bool run_action_(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, const std::vector<const char*>& opts,
                         amd_comgr_data_set_t in, amd_comgr_data_set_t out, std::string& log);
 
-// DCSG_JIT_PROFILE=1: seconds per comgr action on stderr (where a cold build spends its time)
+// DCSG_JIT_PROFILE=1: seconds per comgr action on stderr (where a cold build spends its time); set per call of
+// jit_scene_module from its JitEnv
+static thread_local bool t_profile = false;
 static bool run_action(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, const std::vector<const char*>& opts,
                        amd_comgr_data_set_t in, amd_comgr_data_set_t out, std::string& log)
 {
-    static const bool profile = getenv("DCSG_JIT_PROFILE") != nullptr;
-    if (!profile) return run_action_(kind, lang, opts, in, out, log);
+    if (!t_profile) return run_action_(kind, lang, opts, in, out, log);
     timespec a, b;
     clock_gettime(CLOCK_MONOTONIC, &a);
     bool ok = run_action_(kind, lang, opts, in, out, log);
@@ -257,6 +266,12 @@ static bool run_action(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, 
 static bool run_action_(amd_comgr_action_kind_t kind, amd_comgr_language_t lang, const std::vector<const char*>& opts,
                         amd_comgr_data_set_t in, amd_comgr_data_set_t out, std::string& log)
 {
+    // One comgr action at a time per PROCESS: two host threads compiling at once (two contexts, or a background build
+    // next to another context's load) write the same globals inside libamd_comgr (ThreadSanitizer, tools/sanitize_host.sh
+    // --thread: a std::string assignment to a library global from both).  Compiles are rare and long; serialising them
+    // costs a second context nothing it would not also lose to the compiler's own locks.
+    static std::mutex comgr_actions;
+    std::lock_guard<std::mutex> lock(comgr_actions);
     amd_comgr_action_info_t info;
     if (comgr().amd_comgr_create_action_info(&info) != AMD_COMGR_STATUS_SUCCESS) {
         log += "comgr: create_action_info failed\n";
@@ -283,8 +298,18 @@ static bool run_action_(amd_comgr_action_kind_t kind, amd_comgr_language_t lang,
     return true;
 }
 
+JitEnv JitEnv::from_environment()
+{
+    JitEnv e;
+    if (const char* o = getenv("DCSG_JIT_EXTRA_OPTS")) e.extra_opts = o;
+    e.cache_dir = getenv("DCSG_JIT_NO_CACHE") ? std::string() : dcsg::cache_dir();
+    e.profile = getenv("DCSG_JIT_PROFILE") != nullptr;
+    e.comgr_paths = comgr_candidates();
+    return e;
+}
+
 bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, std::string& hsaco, std::string& log,
-                      bool* from_cache, bool relaxed, bool spec_set, int part, bool cache_only)
+                      bool* from_cache, bool relaxed, bool spec_set, int part, bool cache_only, const JitEnv* env)
 {
     if (from_cache) *from_cache = false;
     std::string kernels_bc;
@@ -298,9 +323,12 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
 
     // Extra compiler options for experiments (';'-separated), e.g. DCSG_JIT_EXTRA_OPTS="-mllvm;-vectorize-slp=false".
     // They take part in the cache key.
+    const JitEnv env_now = env ? JitEnv() : JitEnv::from_environment();
+    const JitEnv& E = env ? *env : env_now;
+    t_profile = E.profile;
     std::vector<std::string> extra_opts;
-    if (const char* e = getenv("DCSG_JIT_EXTRA_OPTS")) {
-        std::string t = e;
+    if (!E.extra_opts.empty()) {
+        std::string t = E.extra_opts;
         size_t i = 0;
         while (i <= t.size()) {
             size_t j = t.find(';', i);
@@ -333,7 +361,7 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
         std::string ident = std::string("\n// isa: ") + kIsa;
         for (auto o : cl_opts) ident += std::string("\n// cl: ") + o;
         for (auto o : cg_opts) ident += std::string("\n// cg: ") + o;
-        ident += "\n// comgr: " + comgr_identity();
+        ident += "\n// comgr: " + comgr_identity(E.comgr_paths);
         source_key = source + ident;
     }
     uint64_t h1 = fnv1a64(source_key.data(), source_key.size(), 0xcbf29ce484222325ull);
@@ -342,7 +370,7 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
     h2 = fnv1a64(kernels_bc.data(), kernels_bc.size(), h2);
     char key[40];
     snprintf(key, sizeof(key), "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
-    const std::string cdir = getenv("DCSG_JIT_NO_CACHE") ? std::string() : cache_dir();
+    const std::string& cdir = E.cache_dir;
     const std::string cpath = cdir.empty() ? std::string() : cdir + "/" + key + ".hsaco";
     if (!cpath.empty() && read_cached_code_object(cpath, hsaco)) {
         if (from_cache) *from_cache = true;
@@ -351,8 +379,9 @@ bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, 
     hsaco.clear();
     if (cache_only) return false;
 
-    if (!comgr().handle || !comgr().error.empty()) {
-        log = "cannot load the ROCm code object manager (libamd_comgr.so.3):\n" + comgr().error;
+    ComgrApi& api = comgr(&E.comgr_paths);
+    if (!api.handle || !api.error.empty()) {
+        log = "cannot load the ROCm code object manager (libamd_comgr.so.3):\n" + api.error;
         return false;
     }
     // 1. brush text (OpenCL C) -> gfx950 bitcode

@@ -1,6 +1,7 @@
 // jit.hpp -- per-scene code object builder (see jit.cpp).
 #pragma once
 #include <string>
+#include <vector>
 
 namespace dcsg {
 std::string library_dir();
@@ -18,7 +19,16 @@ bool read_file(const std::string& path, std::string& out);
 // the rest while the export already runs (dcsg_api.cpp: load_rest_part).
 // cache_only: never compile; returns false (log empty) when the code object is not in the cache.
 enum { JIT_PART_EXPORT = 0, JIT_PART_REST = 1 };
+// The JIT's environment switches, read ONCE on the caller's thread: a background build must not call getenv while the
+// host (or a test) may call setenv -- a libc data race.  env == nullptr: read the environment now.
+struct JitEnv {
+    std::string extra_opts;  // DCSG_JIT_EXTRA_OPTS
+    std::string cache_dir;   // the resolved cache directory; empty = no cache (DCSG_JIT_NO_CACHE, or no usable directory)
+    bool profile = false;    // DCSG_JIT_PROFILE
+    std::vector<std::string> comgr_paths;  // where libamd_comgr is looked for (DCSG_COMGR_PATH, ROCM_PATH, defaults)
+    static JitEnv from_environment();
+};
 bool jit_scene_module(const std::string& scene_cl, const std::string& extra_cl, std::string& hsaco, std::string& log,
                       bool* from_cache, bool relaxed = false, bool spec_set = false, int part = JIT_PART_EXPORT,
-                      bool cache_only = false);
+                      bool cache_only = false, const JitEnv* env = nullptr);
 }  // namespace dcsg

@@ -175,22 +175,6 @@ extern "C" __device__ float dcsg_spec_eval1(float x, float y, float z);
 // leave out terms with a zero coefficient, which is exact for finite coordinates only -- specialise.cpp)
 extern "C" __device__ float dcsg_spec_eval1x(float x, float y, float z);
 extern "C" __device__ int dcsg_spec_small();  // 1: few objects, row-invariant stencil terms may stay in registers
-// Four lattice points per lane (dcsg_run4).  Generated for scenes of standard brushes with at most four object
-// evaluations (dcsg_spec_row4_ok() = 1), stubs otherwise.  dcsg_spec_row4: element
-// 7 j + k = lattice point j (x.s<j>, y, z) at stencil point k; elements 28 / 29 = unsigned minimum / maximum of the bits
-// of the square roots' first estimates (scene_prelude.cl: dcsg_sqrt_acc).  dcsg_spec_row4_d: the four SDF values, then
-// the same two words.
-typedef float dcsg_cl_float4 __attribute__((ext_vector_type(4)));
-typedef float dcsg_cl_float32 __attribute__((ext_vector_type(32)));
-extern "C" __device__ dcsg_cl_float32 dcsg_spec_row4(dcsg_cl_float4 x, float y, float z);
-extern "C" __device__ dcsg_cl_float8 dcsg_spec_row4_d(dcsg_cl_float4 x, float y, float z);
-// the same with every point's own y and z (a run that crosses a row end)
-extern "C" __device__ dcsg_cl_float32 dcsg_spec_row4g(dcsg_cl_float4 x, dcsg_cl_float4 y, dcsg_cl_float4 z);
-extern "C" __device__ dcsg_cl_float8 dcsg_spec_row4g_d(dcsg_cl_float4 x, dcsg_cl_float4 y, dcsg_cl_float4 z);
-// dcsg_spec_eval7 with the standard brushes inline and the deferred guard: elements 0..6 the values, 8 / 9 the two words
-typedef float dcsg_cl_float16 __attribute__((ext_vector_type(16)));
-extern "C" __device__ dcsg_cl_float16 dcsg_spec_eval7a(dcsg_cl_float8 px, dcsg_cl_float8 py, dcsg_cl_float8 pz);
-extern "C" __device__ int dcsg_spec_row4_ok();
 #define DCSG_HAVE_SPEC 1
 #endif
 #else
@@ -497,58 +481,6 @@ __device__ __forceinline__ void dcsg_finish_normal(float Dx, float Dy, float Dz,
     dcsg_normalize_plain(nx, ny, nz, len);
 }
 #endif
-
-// dcsg_finish_normal's fast path WITHOUT its own branch, for code that finishes several normals side by side (the row
-// kernels): the operand tests are folded into running unsigned minima / maxima -- gmn / gmx: bits of the square root's
-// first estimate (dcsg_sqrt); smn: bits of the smallest |component|; lmx: bits of the length -- and the caller tests them
-// once (dcsg_normal_acc_bad); where the test fails it recomputes through dcsg_finish_normal.  Same bits wherever it passes.
-struct DcsgNormalAcc {
-    unsigned int gmn, gmx, smn, lmx;
-};
-__device__ __forceinline__ DcsgNormalAcc dcsg_normal_acc_init(unsigned int gmn, unsigned int gmx)
-{
-    return {gmn, gmx, 0xffffffffu, 0x3f800000u};
-}
-__device__ __forceinline__ bool dcsg_normal_acc_bad(const DcsgNormalAcc& a)
-{
-    // square roots: 2^-48 <= g < inf; normalize (dcsg_normalize_fast): every component a zero or >= 2^-60 in magnitude
-    // (dcsg_component_key), length <= 2^60 (a NaN component makes the length NaN, and the zero vector's squared length 0
-    // gives rsq(0) * 0 = NaN: both fail the gmx test)
-    return a.gmn < 0x27800000u || a.gmx >= 0x7f800000u || a.smn < DCSG_KEY_ORDINARY || a.lmx > 0x5d800000u;
-}
-__device__ __forceinline__ void dcsg_finish_normal_acc(float Dx, float Dy, float Dz, float& nx, float& ny, float& nz, DcsgNormalAcc& a)
-{
-#ifdef DCSG_RELAXED
-    dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
-#else
-    const float twoE = (float)(2.0 * K2_NORMAL_EPSILON);
-    const double k = 1.0 / (double)twoE;
-    const float kh = (float)k, kl = (float)(k - (double)kh);
-    nx = __builtin_fmaf(kh, Dx, kl * Dx);
-    ny = __builtin_fmaf(kh, Dy, kl * Dy);
-    nz = __builtin_fmaf(kh, Dz, kl * Dz);
-    const float q = nx * nx + ny * ny + nz * nz;
-    float y = __builtin_amdgcn_rsqf(q);
-    float g = q * y;
-    float h = 0.5f * y;
-    float d = __builtin_fmaf(-g, g, q);
-    const float len = __builtin_fmaf(d, h, g);
-    const unsigned int gb = __float_as_uint(g), lb = __float_as_uint(len);
-    const unsigned int s0 = dcsg_component_key(nx), s1 = dcsg_component_key(ny), s2 = dcsg_component_key(nz);
-    a.gmn = gb < a.gmn ? gb : a.gmn;
-    a.gmx = gb > a.gmx ? gb : a.gmx;
-    unsigned int sm = s0 < s1 ? s0 : s1;
-    sm = s2 < sm ? s2 : sm;
-    a.smn = sm < a.smn ? sm : a.smn;
-    a.lmx = lb > a.lmx ? lb : a.lmx;
-    float r = __builtin_amdgcn_rcpf(len);
-    float e = __builtin_fmaf(-len, r, 1.0f);
-    float r1 = __builtin_fmaf(e, r, r);
-    nx = __builtin_copysignf(dcsg_div_by(nx, len, r1), nx);
-    ny = __builtin_copysignf(dcsg_div_by(ny, len, r1), ny);
-    nz = __builtin_copysignf(dcsg_div_by(nz, len, r1), nz);
-#endif
-}
 
 // get_normal, k2.cl:149-179
 __device__ __forceinline__ void dcsg_get_normal(const SceneLds& s, float x, float y, float z, float& nx, float& ny,
@@ -1034,20 +966,12 @@ __device__ __forceinline__ void dcsg_cache_step_bounds(const SceneLds& s, const 
 struct DcsgTileReach {
     float cx, cy, cz, ax, ay, az;
 };
-__device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool valid, float x, float y, float z, float pad,
-                                                      unsigned short* list, float grow, DcsgTileReach& reach)
+// The list for an explicit tile: centre (cx, cy, cz), half extents (hx, hy, hz) INCLUDING the stencil's pad.
+__device__ __forceinline__ int dcsg_build_active_list_box(const SceneLds& s, float cx, float cy, float cz, float hx, float hy, float hz,
+                                                          unsigned short* list)
 {
     const int lane = threadIdx.x & (DCSG_WAVE - 1);
     const float inf = __builtin_inff();
-    float x0 = wave_min_f(valid ? x : inf), x1 = wave_max_f(valid ? x : -inf);
-    float y0 = wave_min_f(valid ? y : inf), y1 = wave_max_f(valid ? y : -inf);
-    float z0 = wave_min_f(valid ? z : inf), z1 = wave_max_f(valid ? z : -inf);
-    float cx = 0.5f * (x0 + x1), cy = 0.5f * (y0 + y1), cz = 0.5f * (z0 + z1);
-    float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0), hz = 0.5f * (z1 - z0);
-    const float extra = grow * (fmaxf(hx, fmaxf(hy, hz)) + pad);
-    hx += extra, hy += extra, hz += extra;
-    reach = {cx, cy, cz, hx, hy, hz};  // before the stencil's pad: where the points themselves may be
-    hx += pad, hy += pad, hz += pad;
     float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
     const int n = s.n_items;
     float top_upper = inf;  // plain unions: the smallest upper bound of all items (dcsg_top_min_upper)
@@ -1114,6 +1038,20 @@ __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool va
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return n_active;
 }
+__device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool valid, float x, float y, float z, float pad,
+                                                      unsigned short* list, float grow, DcsgTileReach& reach)
+{
+    const float inf = __builtin_inff();
+    float x0 = wave_min_f(valid ? x : inf), x1 = wave_max_f(valid ? x : -inf);
+    float y0 = wave_min_f(valid ? y : inf), y1 = wave_max_f(valid ? y : -inf);
+    float z0 = wave_min_f(valid ? z : inf), z1 = wave_max_f(valid ? z : -inf);
+    float cx = 0.5f * (x0 + x1), cy = 0.5f * (y0 + y1), cz = 0.5f * (z0 + z1);
+    float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0), hz = 0.5f * (z1 - z0);
+    const float extra = grow * (fmaxf(hx, fmaxf(hy, hz)) + pad);
+    hx += extra, hy += extra, hz += extra;
+    reach = {cx, cy, cz, hx, hy, hz};  // before the stencil's pad: where the points themselves may be
+    return dcsg_build_active_list_box(s, cx, cy, cz, hx + pad, hy + pad, hz + pad, list);
+}
 #define DCSG_HAVE_CULL 1
 #endif
 
@@ -1163,37 +1101,6 @@ __device__ __forceinline__ void dcsg_stencil_spec(float x, float y, float z, boo
 }
 #endif
 
-#if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
-// MEASURED AND NOT KEPT (round 3; DCSG_SWEEP_FORM=merged in a -DDCSG_SWEEP_FORMS build): 136 instead of 146 VALU
-// instructions per lattice point, 60 % instead of 76 % VALU utilisation, 6 % slower.
-// dcsg_stencil_spec<true> (SDF + normal) for scenes of standard brushes on a lattice without a -0.0 coordinate (the host's
-// DCSG_SWEEP_NO_NEG_ZERO check): the seven square roots of the brushes and the normalisation run in one basic block, their
-// operand tests merged into one ballot per point (dcsg_spec_eval7a, dcsg_finish_normal_acc) instead of eight
-// compare-and-branch pairs; a wave that fails the test recomputes through the guarded code.  Same bits.
-__device__ __forceinline__ void dcsg_stencil_spec_merged(float x, float y, float z, float& sdf, float& nx, float& ny, float& nz)
-{
-    const float e = (float)K2_NORMAL_EPSILON;
-    float xp = x + e, xm = x - e, yp = y + e, ym = y - e, zp = z + e, zm = z - e;
-    dcsg_cl_float8 px = {x, xp, xm, x, x, x, x, 0.0f};
-    dcsg_cl_float8 py = {y, y, y, yp, ym, y, y, 0.0f};
-    dcsg_cl_float8 pz = {z, z, z, z, z, zp, zm, 0.0f};
-    dcsg_cl_float16 o = dcsg_spec_eval7a(px, py, pz);
-    DcsgNormalAcc acc = dcsg_normal_acc_init(__float_as_uint(o[8]), __float_as_uint(o[9]));
-    sdf = o[0];
-    dcsg_finish_normal_acc(o[1] - o[2], o[3] - o[4], o[5] - o[6], nx, ny, nz, acc);
-#ifdef DCSG_SCHED_SPREAD_TRANS
-    // experiment: ask the scheduler to spread the nine quarter-rate instructions (7 + 1 rsq, 1 rcp) over the block, each
-    // followed by DCSG_SCHED_SPREAD_TRANS plain VALU instructions, instead of bunching them
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);                        // 1 TRANS
-        __builtin_amdgcn_sched_group_barrier(0x2, DCSG_SCHED_SPREAD_TRANS, 0);    // n VALU
-    }
-#endif
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(dcsg_normal_acc_bad(acc)) != 0ull, 0))
-        dcsg_stencil_spec<true>(x, y, z, true, true, sdf, nx, ny, nz);
-}
-#endif
 
 // ISV3D64::getPoint, ISV.hpp:103-109
 __device__ __forceinline__ float dcsg_lattice_coord(const DcsgLattice& L, int axis, int i)
@@ -1302,26 +1209,13 @@ __device__ __forceinline__ void dcsg_wave_advance(unsigned int n1, unsigned int&
 }
 
 // write-once streaming output: non-temporal stores (nothing in the sweeps reads the lattice back)
-#ifdef DCSG_NO_NT_STORES
-#define DCSG_STREAM_STORE(v, p) (*(p) = (v))
-#else
 #define DCSG_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#endif
 // The sweeps' stores as "scalar base + 32-bit lane offset" (global_store ... s[base:base+1]): a wave's base is uniform (SGPRs,
 // advanced by scalar adds), so a pass spends no vector instruction on addresses -- left to itself the compiler keeps
 // "pointer + lane" in a VGPR pair and pays two 64-bit vector adds per pass (a v_mad_u64_u32 in the general path).  Sphere
 // fused 513^3 0.458 -> 0.450 ms, 1025^3 3.54 -> 3.47 (profiles/r03_ab/r03_ab_stores2.txt, r03_ab_saddr.txt).  Used by the
 // SDF + normal sweep of per-scene code only: the SDF-only sweep (+3-4 %) and the interpreters (+1 %) were slower with it.
 // `base` MUST be wave-uniform.
-#ifdef DCSG_NO_SADDR_STORES  // A/B builds
-__device__ __forceinline__ void dcsg_store_lane(float* base, unsigned int& lane4, float v) { DCSG_STREAM_STORE(v, base + lane4 / 4u); }
-__device__ __forceinline__ void dcsg_store3_lane(float* base, unsigned int& lane12, float a, float b, float c)
-{
-    DCSG_STREAM_STORE(a, base + lane12 / 4u);
-    DCSG_STREAM_STORE(b, base + lane12 / 4u + 1);
-    DCSG_STREAM_STORE(c, base + lane12 / 4u + 2);
-}
-#else
 // SGPR copy of a wave-uniform pointer (folds away where the compiler already knows the value to be uniform), made opaque
 // by an empty asm so that the compiler cannot fold "base + lane" back into a loop-carried VGPR pointer: the stores below
 // are then ordinary compiler-generated instructions of the form global_store ... v_off, v_data, s[base:base+1] (all of the
@@ -1358,83 +1252,6 @@ __device__ __forceinline__ void dcsg_store3_lane(float* base, unsigned int& lane
     DCSG_STREAM_STORE(b, o + 1);
     DCSG_STREAM_STORE(c, o + 2);
 }
-#endif
-// A/B builds only (timing, wrong output): -DDCSG_EXPERIMENT_NOSTORE runs the sweeps' arithmetic WITHOUT their store stream --
-// the stores sit behind a test of the computed values that no lattice point passes, so nothing is sunk or dropped
-// (profiles/r03_ab/r03_ab_nostore.txt: what the store stream costs the fused sweep).
-#ifdef DCSG_EXPERIMENT_NOSTORE
-#define DCSG_STORE_GATE(a, b, c, d) if (__builtin_amdgcn_ballot_w64((a) + (b) + (c) + (d) == 1.0e30f) != 0ull)
-#else
-#define DCSG_STORE_GATE(a, b, c, d)
-#endif
-
-#if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
-// ---------------------------------------------------------------------------
-// MEASURED AND NOT KEPT (round 3): compiled only with -DDCSG_SWEEP_FORMS (tools/make_ab_tree.sh), selected at run time by
-// DCSG_SWEEP_FORM=run4.  Fewer instructions, more time: profiles/r03_ab_forms.txt, r03_pmcq_clk_*.txt, DESIGN.md.
-// Four lattice points per lane for store-bound scenes (standard brushes, at most four object evaluations:
-// dcsg_spec_row4_ok()): in a run of 256 consecutive points a LANE OWNS the points lane, lane + 64, lane + 128, lane + 192,
-// i.e. its share of each of the run's four 64-point passes, so that the stores keep the flat kernel's shape (per
-// instruction a wave writes 256 contiguous, 256-byte-aligned bytes of SDF or 768 of normals) while
-//   * the 28 (SDF only: 4) square roots and the 4 normalisations run side by side in one basic block, their operand tests
-//     folded into four running minima / maxima that are tested ONCE per run (dcsg_normal_acc_bad) -- the per-root
-//     compare-and-branch of dcsg_sqrt is gone and the chains are free to overlap; a wave that fails the test (tiny, zero,
-//     huge or NaN operands: lattice points on a symmetry plane of the scene, where a gradient component is exactly zero)
-//     recomputes its four points through the guarded code, so the results are bit-identical to it everywhere;
-//   * in a run that lies inside one lattice row, y and z and everything the seven stencil evaluations derive from them
-//     alone are shared by the lane's four points (value numbering over dcsg_spec_row4's straight-line code: same
-//     operations, same bits); a run that crosses a row end takes dcsg_spec_row4g, every point with its own y and z.
-// What did NOT work, measured (profiles/r03_ab_rows.txt, tools/write_patterns2.hip): runs aligned to the lattice ROWS
-// (segments of 256 points starting at a row start) -- rows hold 2^k + 1 points, so every store then starts at an odd
-// 4-byte offset, every instruction leaves two partial 128-byte lines to another wave, and the sweep takes 1.5-2x as
-// long; a lane owning four CONSECUTIVE points with 16-byte stores at a 48-byte stride for the normals: 0.70 of the
-// HBM peak as plain stores and 0.27 as non-temporal ones, against 0.80 for the pattern kept here.
-// The host sets DCSG_SWEEP_NO_NEG_ZERO only for lattices without a -0.0 coordinate (the stencil's "+ 0.0f" would change it:
-// dcsg_stencil_spec).
-// ---------------------------------------------------------------------------
-// x, y, z: the lane's four points (pass j of the run); in_row: y and z are the same for all four (wave-uniform)
-template <int MODE>
-__device__ __forceinline__ void dcsg_run4(const dcsg_cl_float4& x, const dcsg_cl_float4& y, const dcsg_cl_float4& z, bool in_row,
-                                          float* __restrict__ sdf_at, float* __restrict__ nrm_at)
-{
-    if (MODE == 1) {
-        dcsg_cl_float8 v = in_row ? dcsg_spec_row4_d(x, y[0], z[0]) : dcsg_spec_row4g_d(x, y, z);
-        const unsigned int gmn = __float_as_uint(v[4]), gmx = __float_as_uint(v[5]);
-        float sd[4] = {v[0], v[1], v[2], v[3]};
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(gmn < 0x27800000u || gmx >= 0x7f800000u) != 0ull, 0)) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) sd[j] = dcsg_spec_eval1(x[j], y[j], z[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) DCSG_STREAM_STORE(sd[j], sdf_at + 64 * j);
-    } else {
-        dcsg_cl_float32 v = in_row ? dcsg_spec_row4(x, y[0], z[0]) : dcsg_spec_row4g(x, y, z);
-        DcsgNormalAcc acc = dcsg_normal_acc_init(__float_as_uint(v[28]), __float_as_uint(v[29]));
-        float sd[4], nx[4], ny[4], nz[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            sd[j] = v[7 * j];
-            dcsg_finish_normal_acc(v[7 * j + 1] - v[7 * j + 2], v[7 * j + 3] - v[7 * j + 4], v[7 * j + 5] - v[7 * j + 6], nx[j], ny[j], nz[j],
-                                   acc);
-        }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(dcsg_normal_acc_bad(acc)) != 0ull, 0)) {
-#pragma unroll 1
-            for (int j = 0; j < 4; j++) {
-                float a = 0.0f, b = 0.0f, c = 0.0f, d = 0.0f;
-                dcsg_stencil_spec<true>(x[j], y[j], z[j], true, true, a, b, c, d);
-                sd[j] = a, nx[j] = b, ny[j] = c, nz[j] = d;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) DCSG_STORE_GATE(sd[j], nx[j], ny[j], nz[j]) {
-            DCSG_STREAM_STORE(sd[j], sdf_at + 64 * j);
-            DCSG_STREAM_STORE(nx[j], nrm_at + 192 * j);
-            DCSG_STREAM_STORE(ny[j], nrm_at + 192 * j + 1);
-            DCSG_STREAM_STORE(nz[j], nrm_at + 192 * j + 2);
-        }
-    }
-}
-#endif
 
 // ---------------------------------------------------------------------------
 // Kernel 1: fused lattice sweep.  One thread per lattice point, x fastest, so a wave stores
@@ -1467,22 +1284,12 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
     // (positions from dcsg_lattice_coord per point, no LDS, no barrier, finer grids) was measured and not kept: 0.110 ms
     // at 513^3 and 0.82 against 0.75 ms at 1025^3 (profiles/r03_ab_notables.txt).
     SceneLds s = K < 0 ? SceneLds{} : dcsg_stage_scene(blob, n_vec4);
-#ifdef DCSG_NO_XONLY  // A/B builds
-    constexpr bool XO = false;
-#else
     constexpr bool XO = K < 0 && MODE == 1;  // SDF-only sweep of per-scene code: x table only (dcsg_stage_axes)
-#endif
     const float* ax = dcsg_stage_axes<XO>(L, axes_off);
     const bool want_sdf = MODE == 0 ? sdf_out != nullptr : true;
     const bool want_nrm = MODE == 0 ? nrm_out != nullptr : MODE == 3;
     const bool no_neg_zero = (flags & DCSG_SWEEP_NO_NEG_ZERO) != 0u;  // host-checked: no -0.0 coordinate on this lattice
     unsigned int lane4 = lane * 4u, lane12 = lane * 12u;              // byte offsets of the lane's outputs (dcsg_store_lane)
-#if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
-    // one merged guard per lattice point (dcsg_stencil_spec_merged): standard brushes, no -0.0 coordinate on the lattice
-    const bool merged = K < 0 && (flags & DCSG_SWEEP_NO_NEG_ZERO) && (flags & DCSG_SWEEP_MERGED) && dcsg_spec_row4_ok();
-#else
-    const bool merged = false;
-#endif
     // (Tiles of T consecutive 1 024-point groups, to decouple the number of blocks from the number of write fronts, were
     // measured and not kept: profiles/r03_ab/r03_ab_groups.txt.)
     for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -1523,57 +1330,18 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             for (int j = 0; j < 4; j++) DCSG_STREAM_STORE(o[j], sdf_out + idx0 + lane + 64 * j);
             continue;
         }
-#if defined(DCSG_HAVE_SPEC) && defined(DCSG_SWEEP_FORMS)
-        if (K < 0 && (MODE == 1 || MODE == 3) && ax && left >= DCSG_RUN && (flags & DCSG_SWEEP_NO_NEG_ZERO) && (flags & DCSG_SWEEP_RUN4) &&
-            dcsg_spec_row4_ok()) {
-            // four points per lane (dcsg_run4): the lane's share of each of the run's four passes
-            dcsg_cl_float4 x4, y4, z4;
-#ifdef DCSG_EXPERIMENT_ALL_IN_ROW  // timing experiment only (wrong values at row ends): every run through the shared-y/z code
-            const bool in_row = true;
-#else
-            const bool in_row = ix0 + DCSG_RUN <= n1;  // wave-uniform
-#endif
-            if (in_row) {
-                const float* xr = ax + ix0 + lane;
-#pragma unroll
-                for (int j = 0; j < 4; j++) x4[j] = xr[64 * j];
-                const float y = dcsg_axis<XO>(L, ax, 1, iy0), z = dcsg_axis<XO>(L, ax, 2, plane0);
-                y4 = y;
-                z4 = z;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    DcsgWavePoint w = dcsg_wave_point<XO>(L, ax, ix0, iy0, plane0, lane);
-                    x4[j] = w.x, y4[j] = w.y, z4[j] = w.z;
-                    dcsg_wave_advance(n1, ix0, iy0, plane0);
-                }
-            }
-            dcsg_run4<MODE>(x4, y4, z4, in_row, sdf_out + idx0 + lane, MODE == 3 ? nrm_out + (size_t)idx0 * 3 + lane * 3u : nullptr);
-            continue;
-        }
-#endif
 #ifdef DCSG_HAVE_SPEC
         // Small scenes: passes that lie inside one lattice row share y and z, so everything the seven stencil evaluations
         // derive from those two alone is computed once for the passes of a row segment (loop-invariant code motion: same
         // operations, same bits), and the per-pass row tests disappear.
         auto row_pass = [&](const float* xrow, float y, float z, unsigned int k) {
             float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
-#ifdef DCSG_EXPERIMENT_NOCOMPUTE  // A/B builds only (timing, wrong output): the sweep's store stream without its arithmetic
-            sd = nz = xrow[k * DCSG_WAVE], nx = y, ny = z;
-#else
-#ifdef DCSG_SWEEP_FORMS
-            if (MODE == 3 && merged) dcsg_stencil_spec_merged(xrow[k * DCSG_WAVE], y, z, sd, nx, ny, nz);
-            else
-#endif
-                dcsg_stencil_spec<true>(xrow[k * DCSG_WAVE], y, z, true, MODE == 3, sd, nx, ny, nz, no_neg_zero);
-#endif
-            DCSG_STORE_GATE(sd, nx, ny, nz) {
-                if (MODE == 3) {
-                    dcsg_store_lane(sdf_out + idx0 + k * DCSG_WAVE, lane4, sd);
-                    dcsg_store3_lane(nrm_out + ((size_t)idx0 + k * DCSG_WAVE) * 3, lane12, nx, ny, nz);
-                } else {
-                    DCSG_STREAM_STORE(sd, (sdf_out + idx0) + lane + k * DCSG_WAVE);
-                }
+            dcsg_stencil_spec<true>(xrow[k * DCSG_WAVE], y, z, true, MODE == 3, sd, nx, ny, nz, no_neg_zero);
+            if (MODE == 3) {
+                dcsg_store_lane(sdf_out + idx0 + k * DCSG_WAVE, lane4, sd);
+                dcsg_store3_lane(nrm_out + ((size_t)idx0 + k * DCSG_WAVE) * 3, lane12, nx, ny, nz);
+            } else {
+                DCSG_STREAM_STORE(sd, (sdf_out + idx0) + lane + k * DCSG_WAVE);
             }
         };
         if (K < 0 && MODE == 1 && ax && left >= DCSG_RUN && ix0 + DCSG_RUN <= n1 && dcsg_spec_small()) {
@@ -1611,33 +1379,23 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
                 if (want_nrm) dcsg_get_normal(s, x, y, z, nx, ny, nz);
 #ifdef DCSG_HAVE_SPEC
             } else if (K < 0) {
-#ifdef DCSG_EXPERIMENT_NOCOMPUTE
-                sd = nz = x, nx = y, ny = z;
-#else
-#ifdef DCSG_SWEEP_FORMS
-                if (MODE == 3 && merged) dcsg_stencil_spec_merged(x, y, z, sd, nx, ny, nz);
-                else
-#endif
-                    dcsg_stencil_spec<true>(x, y, z, want_sdf, want_nrm, sd, nx, ny, nz, no_neg_zero);
-#endif
+                dcsg_stencil_spec<true>(x, y, z, want_sdf, want_nrm, sd, nx, ny, nz, no_neg_zero);
 #endif
             } else {
                 dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, want_sdf, want_nrm, sd, nx, ny, nz);
             }
             // write-once streaming output: non-temporal stores (nothing in this kernel reads the lattice back)
-            DCSG_STORE_GATE(sd, nx, ny, nz) {
-                if (K < 0 && MODE == 3) {
-                    dcsg_store_lane(sdf_out + at, lane4, sd);
-                    dcsg_store3_lane(nrm_out + (size_t)at * 3, lane12, nx, ny, nz);
-                } else {
-                    // wave-uniform base + lane: the store addresses cost no per-lane multiplies
-                    if (want_sdf) DCSG_STREAM_STORE(sd, (sdf_out + at) + lane);
-                    if (want_nrm) {
-                        float* o = nrm_out + (size_t)at * 3 + lane * 3u;
-                        DCSG_STREAM_STORE(nx, o);
-                        DCSG_STREAM_STORE(ny, o + 1);
-                        DCSG_STREAM_STORE(nz, o + 2);
-                    }
+            if (K < 0 && MODE == 3) {
+                dcsg_store_lane(sdf_out + at, lane4, sd);
+                dcsg_store3_lane(nrm_out + (size_t)at * 3, lane12, nx, ny, nz);
+            } else {
+                // wave-uniform base + lane: the store addresses cost no per-lane multiplies
+                if (want_sdf) DCSG_STREAM_STORE(sd, (sdf_out + at) + lane);
+                if (want_nrm) {
+                    float* o = nrm_out + (size_t)at * 3 + lane * 3u;
+                    DCSG_STREAM_STORE(nx, o);
+                    DCSG_STREAM_STORE(ny, o + 1);
+                    DCSG_STREAM_STORE(nz, o + 2);
                 }
             }
         };
@@ -2140,10 +1898,12 @@ extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P, const float* __restrict__ nodes,
                    unsigned int n_nodes, const float* __restrict__ sdf, const float* __restrict__ nrm,
                    const unsigned char* __restrict__ tri_table, unsigned short* __restrict__ info,
-                   unsigned int* __restrict__ block_sums, unsigned long long* __restrict__ level_stats)
+                   unsigned int* __restrict__ block_sums, unsigned long long* __restrict__ level_stats, int corner_off)
 {
     SceneLds scene = dcsg_stage_scene(blob, n_vec4);
-    __shared__ float corner_normals[8 * 4 * DCSG_BLOCK];  // [corner][x, y, z, length][thread]
+    // [corner][x, y, z, length][thread]: 32 KiB of the dynamic allocation behind the scene's area, at byte `corner_off`;
+    // -1 when a scene with more than a thousand objects leaves no room for it (the edge test then samples per edge end)
+    float* corner_normals = corner_off >= 0 ? reinterpret_cast<float*>(reinterpret_cast<char*>(dcsg_lds) + corner_off) : nullptr;
     Sampler S = {&P, sdf, nrm, &scene};
     unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x;
     unsigned int code = NODE_SKIP, lookup = 0, n_tri = 0;
@@ -2198,27 +1958,45 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
                     // they are sampled once (an on-demand normal is six evaluations of the scene).
                     if (!subdivide) {
                         // the corner loop is rolled (one copy of the evaluation code, see above); the eight normals and
-                        // their lengths wait in LDS, slot-major so that every access is conflict-free
-#pragma unroll 1
-                        for (int k = 0; k < 8; k++) {
-                            float p[3], n[3];
-                            dcsg_corner(k, 1.0f, c, P.hd, p);
-                            sample_normal(S, p, n);
-                            float* o = corner_normals + (size_t)k * 4 * DCSG_BLOCK + threadIdx.x;
-                            o[0] = n[0];
-                            o[DCSG_BLOCK] = n[1];
-                            o[2 * DCSG_BLOCK] = n[2];
-                            o[3 * DCSG_BLOCK] = dcsg_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                        }
-#pragma unroll 1
-                        for (int e = 0; e < 12; e++) {
-                            const float* a = corner_normals + (size_t)dcsg_edge_a(e) * 4 * DCSG_BLOCK + threadIdx.x;
-                            const float* b = corner_normals + (size_t)dcsg_edge_b(e) * 4 * DCSG_BLOCK + threadIdx.x;
-                            float mm = a[3 * DCSG_BLOCK] * b[3 * DCSG_BLOCK];
+                        // their lengths wait in LDS, slot-major so that every access is conflict-free.  Without the LDS
+                        // area the same call site serves the 24 edge ends in turn (a: even k, b: odd k), as the
+                        // reference's loop does: three times the samples, no storage.
+                        const bool lds_normals = corner_normals != nullptr;  // block-uniform
+                        float pa[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        auto edge_test = [&](float ax, float ay, float az, float al, float bx, float by, float bz, float bl) {
+                            float mm = al * bl;
                             if (!(mm < 1e-6f)) {
-                                float q = (a[0] * b[0] + a[DCSG_BLOCK] * b[DCSG_BLOCK] + a[2 * DCSG_BLOCK] * b[2 * DCSG_BLOCK]) / mm;
+                                float q = (ax * bx + ay * by + az * bz) / mm;
                                 // (float)acos((double)q) > threshold, folded by the host into q_star
                                 if (q >= -1.0f && q <= P.q_star) subdivide = true;
+                            }
+                        };
+#pragma unroll 1
+                        for (int k = 0; k < (lds_normals ? 8 : 24); k++) {
+                            float p[3], n[3];
+                            const int corner = lds_normals ? k : ((k & 1) ? dcsg_edge_b(k >> 1) : dcsg_edge_a(k >> 1));
+                            dcsg_corner(corner, 1.0f, c, P.hd, p);
+                            sample_normal(S, p, n);
+                            const float len = dcsg_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                            if (lds_normals) {
+                                float* o = corner_normals + (size_t)k * 4 * DCSG_BLOCK + threadIdx.x;
+                                o[0] = n[0];
+                                o[DCSG_BLOCK] = n[1];
+                                o[2 * DCSG_BLOCK] = n[2];
+                                o[3 * DCSG_BLOCK] = len;
+                            } else if (k & 1) {
+                                edge_test(pa[0], pa[1], pa[2], pa[3], n[0], n[1], n[2], len);
+                            } else {
+                                pa[0] = n[0], pa[1] = n[1], pa[2] = n[2], pa[3] = len;
+                            }
+                        }
+                        if (lds_normals) {
+#pragma unroll 1
+                            for (int e = 0; e < 12; e++) {
+                                const float* a = corner_normals + (size_t)dcsg_edge_a(e) * 4 * DCSG_BLOCK + threadIdx.x;
+                                const float* b = corner_normals + (size_t)dcsg_edge_b(e) * 4 * DCSG_BLOCK + threadIdx.x;
+                                edge_test(a[0], a[DCSG_BLOCK], a[2 * DCSG_BLOCK], a[3 * DCSG_BLOCK], b[0], b[DCSG_BLOCK], b[2 * DCSG_BLOCK],
+                                          b[3 * DCSG_BLOCK]);
                             }
                         }
                     }
@@ -2739,6 +2517,30 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
         }
         dcsg_node_axes(L, i0, side, tab);
         const size_t base = ((size_t)i0[2] * n1 + (size_t)i0[1]) * n1 + (size_t)i0[0];
+        if (!nrm_out && sdf_out) {
+            // SDF only (what an export sweeps): a lane carries FOUR of the node's points through one interpretation of the
+            // list -- the entry decode (LDS record, readfirstlane, brush branch: a chain of dependent LDS reads and scalar
+            // moves per entry) is paid per 1 024 points instead of per 256, and four independent evaluations overlap.
+            // Same arithmetic per point: same bits.
+            for (unsigned int p0 = 0; p0 < pts; p0 += 4u * DCSG_BLOCK) {
+                float px[4], py[4], pz[4], o[4];
+                size_t at[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned int p = p0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x;
+                    const unsigned int cp = p < pts ? p : pts - 1u;  // idle lanes evaluate the last point and store nothing
+                    unsigned int lx, ly, lz;
+                    dcsg_node_local(g, cp, lx, ly, lz);
+                    px[j] = tab[lx], py[j] = tab[DCSG_NODE_TAB + ly], pz[j] = tab[2 * DCSG_NODE_TAB + lz];
+                    at[j] = base + ((size_t)lz * n1 + ly) * n1 + lx;
+                }
+                dcsg_interp<4, 4>(s, px, py, pz, o, list, n_list);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (p0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x < pts) sdf_out[at[j]] = o[j];
+            }
+            continue;
+        }
         for (unsigned int p0 = 0; p0 < pts; p0 += DCSG_BLOCK) {
             unsigned int p = p0 + threadIdx.x;
             bool valid = p < pts;
@@ -2850,6 +2652,324 @@ dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ 
         }
     }
 }
+
+#ifdef DCSG_PART_EXPORT
+// ---------------------------------------------------------------------------
+// Cell lists: the projection of many-object scenes (and whatever else evaluates them at scattered points).
+//
+// dcsg_project_c4 builds its list per WAVE, over the box of the wave's 64 vertices: a wave whose vertices lie far apart
+// (the order of the distinct vertices follows the octree, which jumps; vertices hop to other objects while they descend)
+// gets the whole scene for all its steps and sets the kernel's duration on its own (round 3: 24 576 waves of 0.17 M
+// cycles each in a kernel of 25 M cycles, VALU 5 % busy).  Here the tile belongs to SPACE, not to a wave: a cube of g^3
+// cells over the scene, every cell with the list of the program's steps that can matter anywhere inside it (the same
+// bounds and the same keep rules as the wave lists: dcsg_build_active_list_box over the cell widened by the stencil),
+// built once per scene by dcsg_cells_build.  A vertex reads the list of the cell it is in -- per LANE: the interpreter
+// below decodes a lane's own entry, so what a lane costs depends on where IT is and on nothing else, and lanes that
+// retire are refilled from a queue of the vertices still waiting (a wave is busy until the queue is empty, not until its
+// slowest vertex has done its fifty steps).  Same steps in the same order with the same arithmetic: same bits.
+// Entry: object | brush << 16 | (opcode - 32) << 24 | (stack depth before the step) << 30; SET_K carries its step index
+// in place of the object (its operands are the two floats of the step record).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int dcsg_cell_entry(const int4& st, unsigned int step_index)
+{
+    const unsigned int op = (unsigned int)(st.x - 32) & 0x3fu;
+    const unsigned int payload = st.x == SOP_SET_K ? step_index : (unsigned int)st.z & 0xffffu;
+    return payload | (((unsigned int)st.y & 0xffu) << 16) | (op << 24) | (((unsigned int)st.w & 1u) << 30);
+}
+
+#define DCSG_CELL_NOT_BUILT 0xffffffffu
+#define DCSG_CELL_CHUNK 512u
+#define DCSG_CELL_COARSE 4u  // a coarse cell = 4 x 4 x 4 fine ones (the grid size is a multiple of 4)
+__device__ __forceinline__ unsigned int dcsg_cell_of(const DcsgCellGrid& G, float x, float y, float z, unsigned int& ix, unsigned int& iy,
+                                                     unsigned int& iz)
+{
+    // points outside the cube, and NaNs: the pseudo-cell g^3 (the whole program)
+    const unsigned int g = (unsigned int)G.g;
+    const float fx = (x - G.x0) * G.inv_cell, fy = (y - G.y0) * G.inv_cell, fz = (z - G.z0) * G.inv_cell, gf = (float)g;
+    const bool inside = fx >= 0.0f && fx < gf && fy >= 0.0f && fy < gf && fz >= 0.0f && fz < gf;
+    if (!inside) return g * g * g;
+    ix = (unsigned int)fx, iy = (unsigned int)fy, iz = (unsigned int)fz;
+    return (iz * g + iy) * g + ix;
+}
+
+// Cells are built where vertices are: want[cell] = 1 asks for a cell, 2 = built.  The cells of the vertices and their 26
+// neighbours (most steps of a descent stay that close).
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_cells_mark(const float* __restrict__ verts, unsigned int n_verts, DcsgCellGrid G, unsigned char* __restrict__ want)
+{
+    const int g = G.g;
+    for (unsigned int v = blockIdx.x * DCSG_BLOCK + threadIdx.x; v < n_verts; v += gridDim.x * DCSG_BLOCK) {
+        unsigned int ix = 0, iy = 0, iz = 0;
+        if (dcsg_cell_of(G, verts[(size_t)v * 3], verts[(size_t)v * 3 + 1], verts[(size_t)v * 3 + 2], ix, iy, iz) == (unsigned int)(g * g * g)) continue;
+        for (int dz = -1; dz <= 1; dz++)
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    const int cx = (int)ix + dx, cy = (int)iy + dy, cz = (int)iz + dz;
+                    if (cx < 0 || cy < 0 || cz < 0 || cx >= g || cy >= g || cz >= g) continue;
+                    unsigned char* w = want + ((size_t)cz * g + cy) * g + cx;
+                    if (*w == 0) *w = 1;  // racing writers all write 1; a built cell (2) is left alone
+                }
+    }
+}
+
+// The wanted cells (want == 1) as a list, so that the build below can deal them out evenly: they are clustered (a surface),
+// and a wave that walked its own stretch of the cube would find all of them or none.  work[0] = count, then the cells.
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_cells_collect(const unsigned char* __restrict__ want, unsigned int n_cells_plus_one, unsigned int* __restrict__ work)
+{
+    const unsigned int lane = threadIdx.x & (DCSG_WAVE - 1u);
+    for (unsigned int c0 = blockIdx.x * DCSG_BLOCK + (threadIdx.x & ~(DCSG_WAVE - 1u)); c0 < n_cells_plus_one; c0 += gridDim.x * DCSG_BLOCK) {
+        const unsigned int cell = c0 + lane;
+        const bool wanted = cell < n_cells_plus_one && want[cell] == 1;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(wanted);
+        if (m == 0ull) continue;
+        unsigned int base = 0u;
+        if (lane == 0u) base = atomicAdd(work, (unsigned int)__popcll(m));
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        if (wanted) work[1u + base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = cell;
+    }
+}
+
+// One wave per wanted cell of dcsg_cells_collect's list.  Behind the g^3 fine cells: cells[g^3] = the whole program, for
+// points outside the cube, then the (g / 4)^3 coarse cells that serve a vertex whose fine cell has not been built (the host
+// asks for all of these once per scene).  counter[0] = entries used, counter[3] = cells built.
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_cells_build(const uint4* __restrict__ blob, int n_vec4, DcsgCellGrid G, uint2* __restrict__ cells,
+                 unsigned int* __restrict__ entries, unsigned int* __restrict__ counter, unsigned int capacity,
+                 unsigned char* __restrict__ want, const unsigned int* __restrict__ work)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    unsigned short* list = dcsg_wave_list(s, n_vec4);
+    const unsigned int lane = threadIdx.x & (DCSG_WAVE - 1u);
+    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / DCSG_WAVE));
+    const unsigned int g = (unsigned int)G.g, n_cells = g * g * g, waves = DCSG_BLOCK / DCSG_WAVE;
+    // a cell's tile: the cell, a hair more than the cell (a point on a face may be filed under either neighbour), the stencil
+    const float h = 0.5f * G.cell * 1.001f + (float)K2_NORMAL_EPSILON * 1.01f;
+    const unsigned int n_work = work[0];
+    // Entry space in chunks: one atomic per DCSG_CELL_CHUNK entries instead of one per cell (every wave of the launch adds
+    // to the same word, and same-address atomics retire one at a time: 75 000 cells took 1.7 ms of which 1.5 were this).
+    unsigned int chunk_at = 0u, chunk_left = 0u, built = 0u;  // wave-uniform
+    for (unsigned int w = blockIdx.x * waves + wave; w < n_work; w += gridDim.x * waves) {
+        const unsigned int cell = work[1u + w];
+        int n;
+        if (cell == n_cells) {
+            n = s.n_stack_steps;
+        } else if (cell > n_cells) {  // a coarse cell: DCSG_CELL_COARSE^3 fine ones
+            const unsigned int gc = g / DCSG_CELL_COARSE, cc = cell - n_cells - 1u;
+            const unsigned int ix = cc % gc, iy = (cc / gc) % gc, iz = cc / (gc * gc);
+            const float side = G.cell * (float)DCSG_CELL_COARSE, hc = 0.5f * side * 1.001f + (float)K2_NORMAL_EPSILON * 1.01f;
+            n = dcsg_build_active_list_box(s, G.x0 + ((float)ix + 0.5f) * side, G.y0 + ((float)iy + 0.5f) * side,
+                                           G.z0 + ((float)iz + 0.5f) * side, hc, hc, hc, list);
+        } else {
+            const unsigned int ix = cell % g, iy = (cell / g) % g, iz = cell / (g * g);
+            n = dcsg_build_active_list_box(s, G.x0 + ((float)ix + 0.5f) * G.cell, G.y0 + ((float)iy + 0.5f) * G.cell,
+                                           G.z0 + ((float)iz + 0.5f) * G.cell, h, h, h, list);
+        }
+        if ((unsigned int)n > chunk_left) {  // what is left of the old chunk stays unused
+            const unsigned int take = (unsigned int)n > DCSG_CELL_CHUNK ? (unsigned int)n : DCSG_CELL_CHUNK;
+            unsigned int base = 0u;
+            if (lane == 0u) base = atomicAdd(counter, take);
+            chunk_at = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            chunk_left = take;
+        }
+        if (chunk_at + (unsigned int)n <= capacity && chunk_at + (unsigned int)n >= chunk_at) {
+            // (otherwise the cell stays wanted: the host sees the counter and makes room)
+            for (unsigned int k = lane; k < (unsigned int)n; k += DCSG_WAVE) {
+                const unsigned int c = cell == n_cells ? k : (unsigned int)list[k];
+                entries[chunk_at + k] = dcsg_cell_entry(s.stack_steps[c], c);
+            }
+            if (lane == 0u) {
+                cells[cell] = make_uint2(chunk_at, (unsigned int)n);
+                want[cell] = 2;
+            }
+            built++;
+        }
+        chunk_at += (unsigned int)n;
+        chunk_left -= (unsigned int)n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the list area is rewritten by the next cell
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (lane == 0u && built) atomicAdd(counter + 3, built);  // cells built (diagnostic)
+}
+
+// primary_sdf at the seven stencil points of get_normal (k2.cl:149-179), each lane running ITS OWN list of steps
+// (entries[first .. first + count), dcsg_cell_entry).  The stack of a culling scene is at most two deep (root accumulator,
+// one group: csrc/scene.cpp builds items only then).  The stencil as the reference forms it, v +- (eps, 0, 0): the
+// other coordinates of a "+" point are c + 0.0f, of a "-" point c - 0.0f = c -- kept apart here, so a -0.0 coordinate
+// needs no special path.
+__device__ __forceinline__ void dcsg_interp_lanes(const SceneLds& s, const unsigned int* __restrict__ entries, unsigned int first,
+                                                  unsigned int count, float x, float y, float z, float (&out)[7])
+{
+    const float e = (float)K2_NORMAL_EPSILON, zero = 0.0f;
+    const float xz = x + zero, yz = y + zero, zz = z + zero;
+    const float px[7] = {x, x + e, x - e, xz, x, xz, x};
+    const float py[7] = {y, yz, y, y + e, y - e, yz, y};
+    const float pz[7] = {z, zz, z, zz, z, z + e, z - e};
+    float top[7], below[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) top[k] = below[k] = 0.0f, out[k] = (float)K2_MAX_DISTANCE;
+    float bk = 0.0f, inv_bk = 0.0f;
+    const unsigned int longest = (unsigned int)wave_max((int)count);
+    unsigned int next = count ? entries[first] : 0u;
+    for (unsigned int it = 0u; it < longest; it++) {
+        const unsigned int ent = next;
+        if (it + 1u < count) next = entries[first + it + 1u];  // the next entry is on its way while this one runs
+        if (it >= count) continue;
+        const int op = (int)((ent >> 24) & 0x3fu) + 32;
+        const bool leaf = op <= SOP_ACC_NEGMAX || (op >= SOP_ACC_SMIN && op <= SOP_ACC_NEGSMAX);
+        if (leaf) {
+            float r[7];
+            const int shape = (int)((ent >> 16) & 0xffu);
+            if (shape == 0 && (s.flags & 1)) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) r[k] = (float)K2_MAX_DISTANCE;
+            } else {
+                const unsigned int obj = ent & 0xffffu;
+                const float4 q0 = s.obj[4u * obj + 0u], q1 = s.obj[4u * obj + 1u], q2 = s.obj[4u * obj + 2u], q3 = s.obj[4u * obj + 3u];
+                float A[7], B[7], C[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++) {
+                    float dx = px[k] - q0.x, dy = py[k] - q0.y, dz = pz[k] - q0.z;  // k2.cl:105-111
+                    A[k] = dx * q1.x + dy * q1.y + dz * q1.z;
+                    B[k] = dx * q2.x + dy * q2.y + dz * q2.z;
+                    C[k] = dx * q3.x + dy * q3.y + dz * q3.z;
+                }
+                dcsg_bank_n<7>(A, B, C, shape, r);
+            }
+            if (op == SOP_PUSH) {
+                if (ent >> 30 & 1u) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++) below[k] = top[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 7; k++) top[k] = r[k];
+            } else if (op == SOP_ACC_MIN) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) top[k] = top[k] < r[k] ? top[k] : r[k];
+            } else if (op == SOP_ACC_MAX) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) top[k] = top[k] > r[k] ? top[k] : r[k];
+            } else if (op == SOP_ACC_NEGMAX) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) {
+                    float nb = -r[k];
+                    top[k] = top[k] > nb ? top[k] : nb;
+                }
+            } else if (op == SOP_ACC_SMIN) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) top[k] = dcsg_smin(top[k], r[k], bk, inv_bk);
+            } else if (op == SOP_ACC_SMAX) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) top[k] = dcsg_smax(top[k], r[k], bk, inv_bk);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 7; k++) top[k] = dcsg_smax(top[k], -r[k], bk, inv_bk);
+            }
+        } else if (op <= SOP_POP_NEGMAX || (op >= SOP_POP_SMIN && op <= SOP_POP_NEGSMAX)) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                float a = below[k], b = top[k];
+                if (op == SOP_POP_MIN) top[k] = a < b ? a : b;
+                else if (op == SOP_POP_MAX) top[k] = a > b ? a : b;
+                else if (op == SOP_POP_NEGMAX) {
+                    float nb = -b;
+                    top[k] = a > nb ? a : nb;
+                } else if (op == SOP_POP_SMIN) top[k] = dcsg_smin(a, b, bk, inv_bk);
+                else if (op == SOP_POP_SMAX) top[k] = dcsg_smax(a, b, bk, inv_bk);
+                else top[k] = dcsg_smax(a, -b, bk, inv_bk);
+            }
+        } else if (op == SOP_EXPORT_TOP) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) out[k] = top[k];
+        } else if (op == SOP_SET_K) {
+            const int4 st = s.stack_steps[ent & 0xffffu];
+            bk = __int_as_float(st.y);
+            inv_bk = __int_as_float(st.z);
+        }
+    }
+}
+
+// performGradientDescent over the cell lists.  A lane owns one vertex at a time; idle lanes are refilled from `queue`
+// (a counter into the vertex array) whenever `refill_at` lanes of the wave are idle, and the wave ends when the queue is
+// empty and its last vertex has retired.  A vertex in a fine cell that has not been built (it has left the neighbourhood
+// it started in) reads the list of the COARSE cell around it -- all of those exist -- and asks for the fine cell
+// (want = 1: the next projection of this scene builds it before it starts).  Every vertex runs exactly the steps
+// dcsg_project_body would run for it.
+#ifndef DCSG_PROJECT_CELLS_WAVES
+#define DCSG_PROJECT_CELLS_WAVES 4
+#endif
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, DCSG_PROJECT_CELLS_WAVES)
+dcsg_project_cells(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ verts, unsigned int n, int steps,
+                   DcsgCellGrid G, const uint2* __restrict__ cells, const unsigned int* __restrict__ entries,
+                   unsigned int* __restrict__ queue, int refill_at, unsigned char* __restrict__ want)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    const unsigned int lane = threadIdx.x & (DCSG_WAVE - 1u);
+    const unsigned int g = (unsigned int)G.g, n_cells = g * g * g, gc = g / DCSG_CELL_COARSE;
+    const unsigned int total_waves = gridDim.x * (DCSG_BLOCK / DCSG_WAVE);
+    DcsgDescent d = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, false, true};
+    unsigned int idx = 0u;
+    int k = 0;
+    bool queue_empty = false;  // wave-uniform
+    // The wave draws vertices from the queue a batch at a time (every wave of the launch adds to the same word, and
+    // same-address atomics retire one at a time) and hands them to its idle lanes as they come free.  Batches shrink with
+    // what is left -- a quarter of an even share, between 16 and 256 -- so that the last ones are small and the waves end
+    // together.
+    unsigned int batch_at = 0u, batch_left = 0u, seen = 0u;  // wave-uniform
+    for (;;) {
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(d.done);
+        const int n_idle = __popcll(idle);
+        if (!queue_empty && (n_idle >= refill_at || idle == ~0ull)) {
+            if (batch_left == 0u) {
+                unsigned int take = (seen < n ? n - seen : 0u) / (4u * total_waves);
+                take = take < 16u ? 16u : (take > 256u ? 256u : take);
+                unsigned int base = 0u;
+                if (lane == 0u) base = atomicAdd(queue, take);
+                batch_at = seen = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                batch_left = batch_at < n ? (n - batch_at < take ? n - batch_at : take) : 0u;
+                if (batch_left == 0u) queue_empty = true;
+            }
+            const unsigned int rank = (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
+            if (d.done && rank < batch_left) {
+                idx = batch_at + rank;
+                d = {verts[(size_t)idx * 3 + 0], verts[(size_t)idx * 3 + 1], verts[(size_t)idx * 3 + 2], 0.0f, 0.0f, 0.0f, false, false};
+                k = 0;
+            }
+            const unsigned int took = (unsigned int)n_idle < batch_left ? (unsigned int)n_idle : batch_left;
+            batch_at += took;
+            batch_left -= took;
+        }
+        if (__builtin_amdgcn_ballot_w64(!d.done) == 0ull) {
+            if (queue_empty) break;
+            continue;
+        }
+        const float x = d.x, y = d.y, z = d.z;
+        unsigned int ix = 0u, iy = 0u, iz = 0u;
+        const unsigned int cell = dcsg_cell_of(G, x, y, z, ix, iy, iz);
+        uint2 cl = d.done ? make_uint2(0u, 0u) : cells[cell];
+        if (!d.done && cl.y == DCSG_CELL_NOT_BUILT) {
+            want[cell] = 1;
+            cl = cells[n_cells + 1u + ((iz / DCSG_CELL_COARSE) * gc + iy / DCSG_CELL_COARSE) * gc + ix / DCSG_CELL_COARSE];
+        }
+        float o[7];
+        dcsg_interp_lanes(s, entries, cl.x, cl.y, x, y, z, o);
+        if (!d.done) {
+            float nx, ny, nz;
+            dcsg_finish_normal(o[1] - o[2], o[3] - o[4], o[5] - o[6], nx, ny, nz);
+            const float m = -o[0];  // v3f_scale(n, -s) then v3f_add, CVector.cpp:128-149
+            dcsg_descent_advance(d, x + m * nx, y + m * ny, z + m * nz, k, steps);
+            k++;
+            if (k == steps) d.done = true;
+            if (d.done) {
+                verts[(size_t)idx * 3 + 0] = d.x;
+                verts[(size_t)idx * 3 + 1] = d.y;
+                verts[(size_t)idx * 3 + 2] = d.z;
+            }
+        }
+    }
+}
+#endif  // DCSG_PART_EXPORT (cell lists)
 #endif
 
 #ifdef DCSG_PART_EXPORT
@@ -3185,8 +3305,7 @@ dcsg_test_sqrt(const float* __restrict__ in, float* __restrict__ out, unsigned i
 }
 
 // Diagnostic: dcsg_finish_normal(in[i], dy, dz) over an array (exhaustive test of the float-only gradient scale).
-// mixed bit 0: odd lanes take the gradient (1, 2, 3) instead, so a wave holds ordinary and extreme operands side by
-// side; bit 1: through dcsg_finish_normal_acc (deferred guard) and its fallback.
+// mixed bit 0: odd lanes take the gradient (1, 2, 3) instead, so a wave holds ordinary and extreme operands side by side.
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_test_normal(const float* __restrict__ in, float* __restrict__ out, unsigned int n, float dy, float dz, int mixed)
 {
@@ -3194,13 +3313,7 @@ dcsg_test_normal(const float* __restrict__ in, float* __restrict__ out, unsigned
         float nx, ny, nz;
         const bool other = (mixed & 1) && (i & 1u);
         const float Dx = other ? 1.0f : in[i], Dy = other ? 2.0f : dy, Dz = other ? 3.0f : dz;
-        if (mixed & 2) {  // the deferred-guard form the four-points-per-lane sweep uses, with its fallback
-            DcsgNormalAcc acc = dcsg_normal_acc_init(0x3f800000u, 0x3f800000u);
-            dcsg_finish_normal_acc(Dx, Dy, Dz, nx, ny, nz, acc);
-            if (__builtin_amdgcn_ballot_w64(dcsg_normal_acc_bad(acc)) != 0ull) dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
-        } else {
-            dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
-        }
+        dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
         out[3u * i] = nx, out[3u * i + 1u] = ny, out[3u * i + 2u] = nz;
     }
 }

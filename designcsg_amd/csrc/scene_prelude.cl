@@ -42,50 +42,6 @@ float dcsg_sqrt_ieee(float x){
     return r;
 }
 #endif
-/* Deferred-guard forms of standard-brush scenes (csrc/specialise.cpp, layouts 1-5; A/B builds only): the same fast sequence WITHOUT its own
- * branch; the range test on the first estimate g (an ordinary input <=> 0x27800000 <= bits(g) < 0x7f800000, see
- * dcsg_sqrt in kernels.hip) is folded into a running unsigned minimum and maximum of bits(g) -- one v_min3_u32 /
- * v_max3_u32 per two square roots -- which the kernel tests once per four lattice points; a wave that fails the test
- * recomputes those points through dcsg_sqrt_ieee.  Same bits wherever the test passes. */
-typedef float dcsg_float32 __attribute__((ext_vector_type(32)));
-#ifdef DCSG_RELAXED
-__attribute__((always_inline)) float dcsg_sqrt_acc(float x, uint* gmn, uint* gmx){ return __builtin_amdgcn_sqrtf(x); }
-#else
-__attribute__((always_inline)) float dcsg_sqrt_acc(float x, uint* gmn, uint* gmx){
-    float y = __builtin_amdgcn_rsqf(x);
-    float g = x * y;
-    float h = 0.5f * y;
-    float d = __builtin_fmaf(-g, g, x);
-    float r = __builtin_fmaf(d, h, g);
-    uint b = as_uint(g);
-    *gmn = b < *gmn ? b : *gmn;
-    *gmx = b > *gmx ? b : *gmx;
-    return r;
-}
-#endif
-/* The five standard brushes (scenecompiler.py:424-425, DesignCSG.py:9-22) in the float forms of dcsg_bank in kernels.hip
- * (bit-equal to the OpenCL text with its double literals: tests/test_gpu_parity.py::test_builtin_bank_equals_jit_bank). */
-__attribute__((always_inline)) float dcsg_std_brush_acc(float x, float y, float z, int shape, uint* gmn, uint* gmx){
-    switch (shape) {
-    case 0: return (float)MAX_DISTANCE;
-    case 1: return 0.0f;
-    case 2: return dcsg_sqrt_acc(x * x + y * y + z * z, gmn, gmx) - 0.5f;
-    case 3: {
-        float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
-        float r = dcsg_sqrt_acc(ax * ax + az * az, gmn, gmx);
-        float a = r - 0.5f, b = ay - 0.5f;
-        return a < b ? b : a;
-    }
-    case 4: {
-        float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
-        float b = ay - 0.5f, c = az - 0.5f;
-        float m = b < c ? c : b;
-        float a = ax - 0.5f;
-        return a < m ? m : a;
-    }
-    default: return 0.0f;
-    }
-}
 float  DCSG_OVL sqrt(float x){ return dcsg_sqrt_ieee(x); }
 double DCSG_OVL sqrt(double x){ return __builtin_sqrt(x); }
 float  DCSG_OVL fabs(float x){ return __builtin_fabsf(x); }

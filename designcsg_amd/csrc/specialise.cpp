@@ -22,15 +22,8 @@ static std::string hexf(float f)
     return buf;
 }
 
-// layout: 0 = N stencil points passed as float8 lanes (N = 7) or one point (N = 1);
-//         1 = four lattice points per lane (kernels.hip: dcsg_run4), SDF + normals: their x (float4), shared y and z, 7 stencil points each
-//             (N = 28, point 7 j + k = lattice point j, stencil point k), standard brushes written inline with the
-//             deferred square-root guard (scene_prelude.cl: dcsg_std_brush_acc);
-//         2 = the same, SDF only: the 4 lattice points (N = 4);
-//         3, 4 = as 1, 2 with every lattice point's own y and z (float4): a run that crosses a row end;
-//         5 = the N = 7 stencil points of ONE lattice point (float8 lanes, as layout 0) with the standard brushes inline
-//             and the deferred square-root guard: returns float16 (o0..o6, 0, bits of gmn, bits of gmx, 0...).
-static void emit_function(const Scene& s, bool null_brush_const, int N, bool simplify, const char* name1, std::string& out, int layout = 0)
+// N stencil points passed as float8 lanes (N = 7) or one point (N = 1)
+static void emit_function(const Scene& s, bool null_brush_const, int N, bool simplify, const char* name1, std::string& out)
 {
     enum {
         PUSH = 32, ACC_MIN = 33, ACC_MAX = 34, ACC_NEGMAX = 35, POP_MIN = 36, POP_MAX = 37, POP_NEGMAX = 38, EXPORT_TOP = 39,
@@ -47,39 +40,13 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
     // call it (the stencil points share sub-expressions with their caller only when it is)
     const bool exact_copy = std::string(name1) == "dcsg_spec_eval1x";  // rare path, kept out of line by its caller
     const char* inl = exact_copy ? "" : "__attribute__((always_inline)) ";
-    const bool gen = layout == 3 || layout == 4, fused4 = layout == 1 || layout == 3, sdf4 = layout == 2 || layout == 4;
-    if (fused4) {
-        out += std::string(inl) + (gen ? "dcsg_float32 dcsg_spec_row4g(float4 x, float4 y, float4 z){\n" : "dcsg_float32 dcsg_spec_row4(float4 x, float y, float z){\n");
-        out += "  const float e = (float)0.005;\n";  // K2_NORMAL_EPSILON, k2.cl:3 (a double literal narrowed, as in get_normal)
-        out += "  const float4 xp = x + e, xm = x - e;\n";
-        out += gen ? "  const float4 yp = y + e, ym = y - e, zp = z + e, zm = z - e;\n" : "  const float yp = y + e, ym = y - e, zp = z + e, zm = z - e;\n";
-        out += "  uint gmn = 0x3f800000u, gmx = 0x3f800000u;\n";
-    } else if (sdf4) {
-        out += std::string(inl) + (gen ? "float8 dcsg_spec_row4g_d(float4 x, float4 y, float4 z){\n" : "float8 dcsg_spec_row4_d(float4 x, float y, float z){\n");
-        out += "  uint gmn = 0x3f800000u, gmx = 0x3f800000u;\n";
-    } else if (layout == 5) {
-        out += std::string(inl) + "float16 dcsg_spec_eval7a(float8 px, float8 py, float8 pz){\n";
-        out += "  uint gmn = 0x3f800000u, gmx = 0x3f800000u;\n";
-    } else if (N == 7)
+    if (N == 7)
         out += std::string(inl) + "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){\n";
     else
         out += std::string(inl) + "float " + name1 + "(float x, float y, float z){\n";
-    auto comp = [&](const std::string& v, int j) { return gen ? v + ".s" + hexdigit[j] : v; };  // y / z: per point or shared
-    auto X = [&](int k) {
-        if (fused4) return std::string(k % 7 == 1 ? "xp.s" : (k % 7 == 2 ? "xm.s" : "x.s")) + hexdigit[k / 7];
-        if (sdf4) return std::string("x.s") + hexdigit[k];
-        return N > 1 ? std::string("px.s") + hexdigit[k] : std::string("x");
-    };
-    auto Y = [&](int k) {
-        if (fused4) return comp(k % 7 == 3 ? "yp" : (k % 7 == 4 ? "ym" : "y"), k / 7);
-        if (sdf4) return comp("y", k);
-        return N > 1 ? std::string("py.s") + hexdigit[k] : std::string("y");
-    };
-    auto Z = [&](int k) {
-        if (fused4) return comp(k % 7 == 5 ? "zp" : (k % 7 == 6 ? "zm" : "z"), k / 7);
-        if (sdf4) return comp("z", k);
-        return N > 1 ? std::string("pz.s") + hexdigit[k] : std::string("z");
-    };
+    auto X = [&](int k) { return N > 1 ? std::string("px.s") + hexdigit[k] : std::string("x"); };
+    auto Y = [&](int k) { return N > 1 ? std::string("py.s") + hexdigit[k] : std::string("y"); };
+    auto Z = [&](int k) { return N > 1 ? std::string("pz.s") + hexdigit[k] : std::string("z"); };
     for (int k = 0; k < N; k++) P("  float o%d = (float)MAX_DISTANCE;\n", k);
     for (int d = 0; d < (s.stack_depth > 0 ? s.stack_depth : 1); d++)
         for (int k = 0; k < N; k++) P("  float s%d_%d = 0.0f;\n", d, k);
@@ -152,12 +119,8 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
                         if (!(simp && o[q] == 0.0f)) out += std::string(" - ") + on[q];
                         out += q < 2 ? ", " : ";\n";
                     }
-                    if (layout)  // standard brush inline, its square root's range test folded into gmn / gmx (one test per row pass)
-                        P("    const float r%d = dcsg_std_brush_acc(%s, %s, %s, %d, &gmn, &gmx);\n", k, row(k, r, "r").c_str(),
-                          row(k, u, "u").c_str(), row(k, f, "f").c_str(), brush);
-                    else
-                        P("    const float r%d = sdf_bank((float3)(%s, %s, %s), (unsigned char)%d);\n", k, row(k, r, "r").c_str(),
-                          row(k, u, "u").c_str(), row(k, f, "f").c_str(), brush);
+                    P("    const float r%d = sdf_bank((float3)(%s, %s, %s), (unsigned char)%d);\n", k, row(k, r, "r").c_str(),
+                      row(k, u, "u").c_str(), row(k, f, "f").c_str(), brush);
                 }
             }
             // `simplify` scenes: right after "PUSH null brush" the accumulator is the constant MAX_DISTANCE and the value
@@ -192,27 +155,11 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
             for (int k = 0; k < N; k++) P("  o%d = s%d_%d;\n", k, depth - 1, k);
         }
     }
-    if (fused4) {
-        out += "  dcsg_float32 res = (dcsg_float32)(0.0f);\n";
-        for (int k = 0; k < N; k++) P("  res[%d] = o%d;\n", k, k);
-        out += "  res[28] = as_float(gmn);\n  res[29] = as_float(gmx);\n  return res;\n}\n";
-    } else if (sdf4) {
-        out += "  return (float8)(o0, o1, o2, o3, as_float(gmn), as_float(gmx), 0.0f, 0.0f);\n}\n";
-    } else if (layout == 5) {
-        out += "  return (float16)(o0, o1, o2, o3, o4, o5, o6, 0.0f, as_float(gmn), as_float(gmx), 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);\n}\n";
-    } else if (N == 7)
+    if (N == 7)
         out += "  return (float8)(o0, o1, o2, o3, o4, o5, o6, 0.0f);\n}\n";
     else
         out += "  return o0;\n}\n";
 }
-
-static const char kRow4Stubs[] =
-    "dcsg_float32 dcsg_spec_row4(float4 x, float y, float z){ return (dcsg_float32)(0.0f); }\n"
-    "float8 dcsg_spec_row4_d(float4 x, float y, float z){ return (float8)(0.0f); }\n"
-    "dcsg_float32 dcsg_spec_row4g(float4 x, float4 y, float4 z){ return (dcsg_float32)(0.0f); }\n"
-    "float8 dcsg_spec_row4g_d(float4 x, float4 y, float4 z){ return (float8)(0.0f); }\n"
-    "float16 dcsg_spec_eval7a(float8 px, float8 py, float8 pz){ return (float16)(0.0f); }\n"
-    "int dcsg_spec_row4_ok(void){ return 0; }\n";
 
 // OpenCL C for dcsg_spec_eval7 / dcsg_spec_eval1.  With `enable` false (or a program that is not
 // stack-disciplined) it emits stubs, which only satisfy the linker: the host never selects the
@@ -225,7 +172,6 @@ std::string specialised_source(const Scene& s, bool null_brush_const, bool enabl
         out += "float dcsg_spec_eval1(float x, float y, float z){ return 0.0f; }\n";
         out += "float dcsg_spec_eval1x(float x, float y, float z){ return 0.0f; }\n";
         out += "int dcsg_spec_small(void){ return 0; }\n";
-        out += kRow4Stubs;
         return out;
     }
     emit_function(s, null_brush_const, 7, simplify, "", out);
@@ -239,21 +185,6 @@ std::string specialised_source(const Scene& s, bool null_brush_const, bool enabl
         if (((op >= 32 && op <= 35) || (op >= 41 && op <= 43)) && !(brush == 0 && null_brush_const)) evals++;
     }
     out += std::string("__attribute__((always_inline)) int dcsg_spec_small(void){ return ") + (evals <= 4 ? "1" : "0") + "; }\n";
-    // Four points per lane / one merged guard per point (kernels.hip: dcsg_run4, dcsg_stencil_spec_merged).  Only for
-    // scenes of standard brushes (`simplify`: their bodies are written inline, so that the square roots' range tests can
-    // be merged) with at most four object evaluations (the dense sweeps of such a scene are store-bound).
-    // (round 3: measured and not kept -- fewer instructions, lower VALU utilisation, more time; the evaluation is generated
-    // only for A/B builds: DCSG_SWEEP_FORMS=1 in the environment and kernels.hip built with -DDCSG_SWEEP_FORMS)
-    if (simplify && evals <= 4 && getenv("DCSG_SWEEP_FORMS") && !getenv("DCSG_NO_ROW4")) {
-        emit_function(s, null_brush_const, 28, simplify, "", out, 1);
-        emit_function(s, null_brush_const, 4, simplify, "", out, 2);
-        emit_function(s, null_brush_const, 28, simplify, "", out, 3);
-        emit_function(s, null_brush_const, 4, simplify, "", out, 4);
-        emit_function(s, null_brush_const, 7, simplify, "", out, 5);
-        out += "__attribute__((always_inline)) int dcsg_spec_row4_ok(void){ return 1; }\n";
-    } else {
-        out += kRow4Stubs;
-    }
     return out;
 }
 

@@ -197,6 +197,12 @@ class Evaluator:
         self._ck(self._L.dcsg_copy_triangles_device(self._h, C.c_void_p(d_out), max_triangles,
                                                     C.c_void_p(stream or None)))
 
+    def debug_cells(self):
+        """Diagnostic: cell lists of the loaded many-object scene (grid, cells built, entries handed out, build ms so far)."""
+        g, nb, e, ms = C.c_int(), C.c_uint64(), C.c_uint64(), C.c_double()
+        self._ck(self._L.dcsg_debug_cells(self._h, C.byref(g), C.byref(nb), C.byref(e), C.byref(ms)))
+        return dict(grid=g.value, cells_built=nb.value, entries=e.value, build_ms=round(ms.value, 3))
+
     def debug_sqrt_device(self, d_in, n, d_out, stream=0):
         self._ck(self._L.dcsg_debug_sqrt_device(self._h, C.c_void_p(d_in), n, C.c_void_p(d_out), C.c_void_p(stream or None)))
 

@@ -236,7 +236,8 @@ const char* dcsg_load_profile(const dcsg_ctx* ctx, int which);
 /* Device time in ms of the most recent TIMED lattice sweep (HIP events on its stream; synchronises): the sweeps of
  * dcsg_eval_lattice and of the exports always are; those of dcsg_sweep_lattice_device only after
  * dcsg_set_sweep_timing(ctx, 1) -- the two event records put several microseconds between back-to-back launches, which an
- * asynchronous caller should not pay by default. */
+ * asynchronous caller should not pay by default.  If the most recent sweep was NOT timed the call fails with
+ * DCSG_ERR_INVALID (it never reports an older sweep's duration). */
 int dcsg_last_sweep_ms(dcsg_ctx* ctx, double* ms);
 int dcsg_set_sweep_timing(dcsg_ctx* ctx, int on);
 
@@ -258,13 +259,23 @@ float dcsg_angle_q_star(float complex_surface_threshold);
 /* Diagnostic: the flags word of the loaded scene's device tables (csrc/scene.cpp build_blob): bit 0 = the null brush is a
  * constant, bit 1 = the root accumulator is a plain union (the tile culling's order-free rule applies). */
 int dcsg_debug_scene_flags(const dcsg_ctx* ctx, int* flags);
+/* Diagnostic: the cell lists of the loaded many-object scene (vertex projection, DESIGN.md "Cell lists"): cells per axis
+ * (0 = no grid yet), cells built (fine, coarse and the pseudo-cell of the whole program) and list entries handed out so far,
+ * host milliseconds spent building cells since the scene was loaded. */
+int dcsg_debug_cells(const dcsg_ctx* ctx, int* grid, uint64_t* cells_built, uint64_t* entries, double* build_ms);
 /* Diagnostic: the kernels' correctly rounded square root over a device array (exhaustive GPU test). */
 int dcsg_debug_sqrt_device(dcsg_ctx* ctx, const float* d_in, size_t n, float* d_out, void* stream);
 /* Diagnostic: the tail of get_normal (k2.cl:175-177: gradient scale in double, normalize) as the kernels compute it,
  * d_out[3i..3i+2] = normal of the gradient (d_in[i], dy, dz); mixed bit 0: odd elements take (1, 2, 3) instead, so a
- * wave holds ordinary and extreme operands together (exhaustive GPU test of the float-only scale); bit 1: through the
- * deferred-guard form (dcsg_finish_normal_acc) and its fallback. */
+ * wave holds ordinary and extreme operands together (exhaustive GPU test of the float-only scale). */
 int dcsg_debug_normal_device(dcsg_ctx* ctx, const float* d_in, size_t n, float dy, float dz, int mixed, float* d_out, void* stream);
+
+/* Diagnostic, no device needed: the host-side sequence of a cold dcsg_load_scene (export part compiled on the calling
+ * thread, rest part by the background job) on a context that never touches HIP, kept in *slot between calls.  mode 0: wait
+ * for the background build; 1: return with it still running (what an early error return leaves behind); 2: destroy the
+ * slot's context.  For the thread-sanitizer harness (tools/sanitize_host.sh --thread) and tests/test_host_threads.py. */
+int dcsg_debug_background_build(void** slot, const char* scene_txt, const char* buildprocedure_txt, const char* scene_cl, int mode,
+                                char* log_out, size_t log_cap);
 
 /* The compile half of Evaluator::build without a device: compiles scene_cl into the on-disk code
  * object cache (used at install time so that known scenes load without compiling).  The compiler

@@ -406,7 +406,8 @@ def test_fused_sweep_with_and_without_the_host_neg_zero_check(ev, oracle, name, 
 
 
 LIGHT_DESIGNS = {
-    # standard brushes only, at most four object evaluations: what the row kernels (dcsg_sweep_rows) are generated for
+    # standard brushes only, at most four object evaluations (dcsg_spec_small): the sweeps keep the row-invariant part of
+    # the seven stencil evaluations across the passes of a row segment
     "sphere_offset": "draw(sphere_brush, Transform.initial(np.array([0.31, -0.17, 0.08]), 0.4, -0.7, 1.1, np.array([0.9, 0.6, 0.75])))",
     "cyl_minus_box": "draw(cylinder_brush, Transform.initial(np.array([0.0, 0.0, 0.0]), 0.0, 0.0, 0.0, np.array([1.0, 1.0, 1.0])))\n"
                      "erase(box_brush, Transform.initial(np.array([0.2, 0.1, -0.3]), 0.7, 0.2, -0.4, np.array([0.5, 0.9, 0.4])))",
@@ -418,12 +419,12 @@ LIGHT_DESIGNS = {
 
 
 @pytest.mark.parametrize("name", ["sphere"] + sorted(LIGHT_DESIGNS))
-def test_row_sweep_bit_exact(ev, oracle, name, tmp_path, monkeypatch):
-    """Dense sweeps of store-bound scenes take the row kernels (a lane owns four consecutive lattice points, square-root
-    and normalisation guards tested once per pass, 16-byte stores) when a row holds at least 256 points.  Whole lattices
-    at 257 points per row against the oracle, bit for bit: SDF + normals, SDF only, Z slabs, a box centred on the
-    scene's symmetry planes (gradient components exactly zero: the merged guard fails and the pass is recomputed through
-    the guarded code) and one that is not, the rows' remainder column; then planes of the 513^3 lattice."""
+def test_light_scene_sweeps_bit_exact(ev, oracle, name, tmp_path):
+    """Dense sweeps of per-scene code for light scenes (standard brushes, at most four object evaluations), whose runs
+    are cut into row segments that share y and z (dcsg_sweep_body: row_pass).  Whole lattices at 257 points per row
+    against the oracle, bit for bit: SDF + normals, SDF only, Z slabs, a box centred on the scene's symmetry planes
+    (gradient components exactly zero) and one that is not, the rows' remainder column; then planes of the 513^3
+    lattice (two row segments and one remainder point per row)."""
     from designcsg_amd.run import run_design
     if name == "sphere":
         load(ev, name)
@@ -450,19 +451,6 @@ def test_row_sweep_bit_exact(ev, oracle, name, tmp_path, monkeypatch):
         assert np.array_equal(bits(gs3), bits(ws[100:131])) and np.array_equal(bits(gn3), bits(wn[100:131]))
         gs4, _ = ev.eval_lattice(c, d, 256, z0=255, z1=257, normals=False)
         assert np.array_equal(bits(gs4), bits(ws[255:257]))
-    # the flat form of the same sweeps gives the same bits (row kernels off: a different scene module)
-    monkeypatch.setenv("DCSG_NO_ROW4", "1")
-    if name == "sphere":
-        load(ev, name)
-    else:
-        assert ev.build_from_dir(wd)[0] == 0
-    fs, fn = ev.eval_lattice(boxes[1][0], boxes[1][1], 256)
-    assert np.array_equal(bits(fs), bits(gs)) and np.array_equal(bits(fn), bits(gn))
-    monkeypatch.delenv("DCSG_NO_ROW4")
-    if name == "sphere":
-        load(ev, name)
-    else:
-        assert ev.build_from_dir(wd)[0] == 0
     # 513 points per row (two segments + one remainder point): the planes around the middle and the last ones
     for z0, z1 in ((250, 262), (509, 513)):
         ws, wn = osc.eval_lattice(center, diameter[0], 512, z0, z1)
@@ -567,6 +555,69 @@ def test_projection_without_lattice(ev, oracle):
     torch.cuda.synchronize()
     want = oracle.Scene.from_dir(scene_dir("design2")).gradient_descent(pts.reshape(-1, 3, 3), 7)
     assert np.array_equal(bits(t.cpu().numpy()), bits(want.reshape(-1, 3)))
+
+
+@pytest.mark.parametrize("name", ["flat256", "grouped256", "smooth256", "mixed_groups"])
+def test_cell_list_projection(ev, oracle, name, monkeypatch):
+    """Many-object scenes project through the cell lists (kernels.hip "Cell lists": a list of steps per cell of a cube
+    over the scene, each LANE interpreting the list of the cell its vertex is in, idle lanes refilled from a queue).
+    Against the oracle, bit for bit, on vertices in no order at all: uniform in the scene, far outside the cube (the
+    pseudo-cell of the whole program), on cell faces, with -0.0 coordinates, NaN and infinity; few and many steps, several
+    grid resolutions and refill thresholds; and against the per-wave lists (DCSG_PROJECT_WAVE_LISTS) it replaces."""
+    import torch
+    monkeypatch.setenv("DCSG_CULL", "8")      # mixed_groups (21 objects) takes the culling kernels too ...
+    monkeypatch.setenv("DCSG_SPECIALISE", "0")  # ... when it is not given per-scene code
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-4.5, 4.5, (20_000, 3)).astype(np.float32)
+    pts[:2000] = rng.uniform(-40, 40, (2000, 3))                  # mostly outside the cube
+    pts[2000:2600] = np.round(pts[2000:2600] * 8) / 8              # on faces of cells of many grids
+    pts[2600:2700, 0] = -0.0
+    pts[2700:2800, 1] = -0.0
+    pts[2800:2900] = (-0.0, -0.0, -0.0)
+    pts[2900] = (np.nan, 0.1, 0.2)
+    pts[2901] = (np.inf, 0.1, 0.2)
+    pts[2902] = (0.3, -np.inf, 1e30)
+    pts[2903] = (1e20, -1e20, 3e38)
+    osc = oracle.Scene.from_dir(scene_dir(name))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def same(a, b):
+        both_nan = np.isnan(a) & np.isnan(b)
+        return np.array_equal(np.where(both_nan, 0, bits(a)), np.where(both_nan, 0, bits(b)))
+
+    with np.errstate(all="ignore"):
+        for steps, n in ((1, 20_000), (9, 20_000), (50, 6_000)):
+            want = osc.gradient_descent(pts[:n - n % 3].reshape(-1, 3, 3), steps).reshape(-1, 3)
+            for env in ({}, {"DCSG_CELLS": "16"}, {"DCSG_CELLS": "97", "DCSG_PROJECT_REFILL": "1"}, {"DCSG_PROJECT_REFILL": "64"},
+                        {"DCSG_PROJECT_WAVE_LISTS": "1"}):
+                if steps == 50 and env and "DCSG_PROJECT_WAVE_LISTS" not in env:
+                    continue
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                load(ev, name)      # the cell lists belong to the loaded scene: a new load builds them again
+                assert ev.scene_info()["interpreter"] == 4
+                t = torch.from_numpy(pts[:len(want)].copy()).cuda()
+                ev.project_vertices_device(t.data_ptr(), len(want), steps, stream)
+                torch.cuda.synchronize()
+                assert same(t.cpu().numpy(), want), (name, steps, env)
+                for k in env:
+                    monkeypatch.delenv(k)
+        # cells are built where vertices go and live as long as the scene: one region, then another (new cells are appended
+        # behind the first ones), then the first again -- with an export in between, which reuses the context's small buffers
+        load(ev, name)
+        halves = [pts[3000:9000][pts[3000:9000, 0] < 0][:1500], pts[3000:9000][pts[3000:9000, 0] >= 0][:1500]]
+        wants = [osc.gradient_descent(h.reshape(-1, 3, 3), 6).reshape(-1, 3) for h in halves]
+        for which in (0, 1, 0):
+            t = torch.from_numpy(halves[which].copy()).cuda()
+            ev.project_vertices_device(t.data_ptr(), len(halves[which]), 6, stream)
+            torch.cuda.synchronize()
+            assert same(t.cpu().numpy(), wants[which]), (name, "region", which)
+            if which == 0:
+                built = ev.debug_cells()
+                assert built["grid"] == 64 and built["cells_built"] > 0
+                ev.export(export_config_text(name, levels=(3, 5, 6), gd=2))
+            else:
+                assert ev.debug_cells()["cells_built"] > built["cells_built"]
 
 
 @pytest.mark.parametrize("n_slabs", [2, 4, 8])
@@ -751,11 +802,10 @@ def test_normal_all_float_inputs(ev, module):
 
 
 @pytest.mark.parametrize("module", ["builtin", "scene"])
-def test_normal_zero_components_and_deferred_guard(ev, module):
-    """(1) Gradients with exactly zero components (lattice points on a symmetry plane of the scene) stay on normalize's
+def test_normal_zero_components(ev, module):
+    """Gradients with exactly zero components (lattice points on a symmetry plane of the scene) stay on normalize's
     fast path: +0 and -0 in every position, next to ordinary lanes, against explicitly rounded double arithmetic, sign of
-    zero included.  (2) The deferred-guard form of the tail (dcsg_finish_normal_acc, what the four-points-per-lane sweep
-    runs) with its fallback, over every 16th block of 2^26 bit patterns of the first component and over the zero cases."""
+    zero included."""
     import torch
     if module == "scene":
         load(ev, "design2")
@@ -773,27 +823,14 @@ def test_normal_zero_components_and_deferred_guard(ev, module):
     x = torch.where(i % 4 == 1, -torch.zeros_like(x), x)
     assert int((x.view(torch.int32) == -(1 << 31)).sum()) == n // 4     # the -0.0 lanes are really -0.0
     for dy, dz in ((0.25, -0.5), (0.0, 3.0), (-0.0, 3.0), (2.0, 0.0), (0.0, -0.0), (0.0, 0.0), (-0.0, -0.0)):
-        for mode in (0, 2):
-            ev.debug_normal_device(x.data_ptr(), n, dy, dz, mode, out.data_ptr(), stream)
-            torch.cuda.synchronize()
-            want = _normal_tail_torch(x, torch.full_like(x, dy), torch.full_like(x, dz))
-            got = out.view(n, 3)
-            for k in range(3):
-                w, q = want[k], got[:, k]
-                same = (w.view(torch.int32) == q.view(torch.int32)) | (torch.isnan(w) & torch.isnan(q))
-                assert bool(same.all()), (dy, dz, mode, k, int((~same).sum()))
-    chunk = 1 << 26
-    out = torch.empty(3 * chunk, dtype=torch.float32, device="cuda")
-    ref = torch.empty(3 * chunk, dtype=torch.float32, device="cuda")
-    for c in range(0, 1 << 32, chunk * 16):
-        xs = (torch.arange(c, c + chunk, dtype=torch.int64, device="cuda") - (1 << 32) * (c >= (1 << 31))).to(torch.int32).view(torch.float32)
-        for mixed in (0, 1):
-            ev.debug_normal_device(xs.data_ptr(), chunk, 0.25, -0.5, mixed, ref.data_ptr(), stream)      # guarded form: held to the
-            ev.debug_normal_device(xs.data_ptr(), chunk, 0.25, -0.5, mixed | 2, out.data_ptr(), stream)  # reference by the test above
-            torch.cuda.synchronize()
-            same = (ref.view(torch.int32) == out.view(torch.int32)) | (torch.isnan(ref) & torch.isnan(out))
-            assert bool(same.all()), (hex(c), mixed, int((~same).sum()))
-
+        ev.debug_normal_device(x.data_ptr(), n, dy, dz, 0, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        want = _normal_tail_torch(x, torch.full_like(x, dy), torch.full_like(x, dz))
+        got = out.view(n, 3)
+        for k in range(3):
+            w, q = want[k], got[:, k]
+            same = (w.view(torch.int32) == q.view(torch.int32)) | (torch.isnan(w) & torch.isnan(q))
+            assert bool(same.all()), (dy, dz, k, int((~same).sum()))
 
 def test_normal_random_gradients(ev):
     """normalize's quotients take one residual correction instead of the IEEE sequence's two (DESIGN.md section 3,
@@ -876,9 +913,11 @@ def test_set_arbitrary_data_after_build(ev, oracle):
     assert np.array_equal(bits(b), bits(osc.eval_sdf(pts)))
 
 
-def test_large_object_tables(built_lib, oracle):
+def test_large_object_tables(built_lib, oracle, lookup_table, monkeypatch):
     """Beyond the reference's MAX_OBJECTS 512 / MAX_BUILD_STEPS 256 (DrawPane.h:14-15): the tables live in LDS, so
-    ~1400 objects fit (160 KiB); more is refused with a clear error instead of overflowing."""
+    ~1400 objects fit (160 KiB); more is refused with a clear error instead of overflowing.  The 1200-object scene also
+    EXPORTS: its tables leave no room for the mesher's 32 KiB of corner normals in LDS, and dcsg_mesh_classify then
+    samples the normals per edge end (same mesh: checked against the oracle, and on a small scene against the LDS form)."""
     from designcsg_amd import _lib
     from designcsg_amd.evaluator import Evaluator
     rng = np.random.default_rng(0)
@@ -901,6 +940,25 @@ def test_large_object_tables(built_lib, oracle):
         gs, gn = e.eval_lattice([0.0, 0.0, 0.0], 10.0, 16)
         ws, wn = osc.eval_lattice([0.0, 0.0, 0.0], 10.0, 16)
         assert np.array_equal(bits(gs), bits(ws)) and np.array_equal(bits(gn), bits(wn))
+        cfg_txt = "10.0\n2\n4\n5\n0.7853981633974483\n3\n16\n512\n4096\n"
+        stats = e.export(cfg_txt)
+        cfg = oracle.parse_export_config(cfg_txt)
+        c, d, _ = osc.estimate_bounding_box(cfg.bounding_box_half_diameter)
+        raw, _ = osc.get_surface(c, d[0], cfg, lookup_table)
+        want = osc.gradient_descent(raw, 3)
+        assert stats.triangles == len(want) > 1000
+        assert np.array_equal(sorted_tris(e.download_triangles()), sorted_tris(want))
+        # the per-edge-end form against the LDS form on a scene that has room for both
+        s2 = read_scene("design1")
+        meshes = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("DCSG_CLASSIFY_NO_LDS_NORMALS", "1")
+            assert e.build(s2["scene.txt"], s2["buildprocedure.txt"], s2["scene.cl"])[0] == 0
+            e.export(export_config_text("design1", levels=(3, 6, 7), gd=2))
+            meshes.append(sorted_tris(e.download_triangles()))
+        monkeypatch.delenv("DCSG_CLASSIFY_NO_LDS_NORMALS")
+        assert len(meshes[0]) > 1000 and np.array_equal(meshes[0], meshes[1])
         st, bp = scene(2400)
         with pytest.raises(_lib.DcsgError) as ei:
             e.build(st, bp, None)

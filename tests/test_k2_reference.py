@@ -279,3 +279,34 @@ def test_hip_path_against_the_reference_kernel_live(ev):
         finally:
             ks.close()
             kd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,res", [("sphere", 512), ("design2", 512), ("design1", 256), ("flat256", 256)])
+def test_lattice_signs_equal_the_reference_kernels_live(ev, name, res):
+    """What the mesher takes from k2 at lattice points is the SIGN (corner cases, edge samples: mesh.hpp:176-183,221-238)
+    and the cull test |d| > 1.1 hd (mesh.hpp:167-170).  Whole export lattice of the scene's stage-A box through the
+    reference kernel and through the HIP sweep: every sign equal, so the octree descends and triangulates alike."""
+    from oracle import ref_k2 as R
+    if name not in _live_scenes():
+        pytest.skip("oracle/_ref/k2_*.hsaco not built (needs /root/reference: build container only)")
+    load(ev, name)
+    c, d, _ = ev.estimate_bounding_box(10.0)
+    got, _ = ev.eval_lattice(c, d, res, normals=False)
+    n1 = res + 1
+    ax = [(np.float32(c[k]) - np.float32(d) * np.float32(0.5)) + (np.float32(d) * np.arange(n1, dtype=np.float32)) / np.float32(res)
+          for k in range(3)]                                                             # ISV.hpp:103-109
+    k = R.RefK2(scene_dir(name), "default", max_points=1 << 24)
+    flips, worst = 0, 0.0
+    try:
+        for z0 in range(0, n1, 32):
+            zs = ax[2][z0:z0 + 32]
+            pts = np.stack(np.broadcast_arrays(ax[0][None, None, :], ax[1][None, :, None], zs[:, None, None]), -1).reshape(-1, 3)
+            want = k.eval_sdf_at_points(pts, local_size=64).reshape(len(zs), n1, n1)
+            g = got[z0:z0 + len(zs)]
+            flips += int(((g < 0) != (want < 0)).sum())
+            worst = max(worst, float(np.abs(g.astype(np.float64) - want).max()))
+    finally:
+        k.close()
+    report("live lattice %s %d^3 points: sign differences vs the reference kernel %d, max |diff| %.3g" % (name, n1, flips, worst))
+    assert flips == 0 and worst <= SDF_TOL

@@ -55,6 +55,7 @@ def main():
                          "mesh": round(st.t_mesh, 4), "project": round(st.t_project, 4),
                          "download": round(st.t_download, 4), "write_stl": round(st.t_write_stl, 4),
                          "write_ply": round(st.t_write_ply, 4), "sweep_kernel_ms": round(st.sweep_kernel_ms, 3)})
+            runs[-1]["cells"] = ev.debug_cells()
         out["triangles"] = int(st.triangles)
         out["lattice_points"] = int(st.lattice_points)
         out["stl_bytes"] = os.path.getsize(os.path.join(tmp, "o.stl"))

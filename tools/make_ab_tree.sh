@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds a second copy of the product tree under tools/_build/<name> with extra defines for kernels.hip, for same-box A/B
-# runs with tools/ab_sweep.py (diagnostic):  bash tools/make_ab_tree.sh treeB "-DDCSG_NO_NT_STORES"
+# runs with tools/ab_sweep.py (diagnostic):  bash tools/make_ab_tree.sh treeB "-DDCSG_C4_WAVES=2"
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; DEFS=$2
