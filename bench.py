@@ -44,6 +44,7 @@ WORKLOADS = {
     "flat256_512": ("flat256", 9, [0.0, 0.0, 0.0], 10.0),
     "flat256_1024": ("flat256", 10, [0.0, 0.0, 0.0], 10.0),
     "grouped256_512": ("grouped256", 9, [0.0, 0.0, 0.0], 10.0),
+    "userbrush128_512": ("userbrush128", 9, [0.0, 0.0, 0.0], 10.0),  # 128 evaluations of the design's own brushes: threaded per-scene code
     "smooth256_512": ("smooth256", 9, [0.0, 0.0, 0.0], 10.0),     # smooth-join extension (no culling)
     "smooth256_1024": ("smooth256", 10, [0.0, 0.0, 0.0], 10.0),
 }
@@ -217,11 +218,13 @@ def export_wall_clock(ev=None):
     exports -- once with the JIT cache warm and once with DCSG_JIT_NO_CACHE=1 (the brush text compiled from scratch).
     Outside the timed region of the headline number."""
     import subprocess
-    d = os.path.join(ROOT, "tests", "golden", "scenes", "design2")
     out = []
-    for levels in ((6, 8, 9), (7, 9, 10)):
-        entry = {"config": "Design2 levels %d/%d/%d (%d^3 voxels)" % (levels + (1 << levels[2],))}
-        for key, extra in (("warm_jit_cache", []), ("cold_jit", ["--cold-jit"])):
+    # Design2 at 512^3 and 1024^3 (BASELINE configs 3, 4), then config 5's two scenes at its stated size
+    for scene, levels in (("design2", (6, 8, 9)), ("design2", (7, 9, 10)), ("flat256", (7, 9, 10)), ("grouped256", (7, 9, 10))):
+        d = os.path.join(ROOT, "tests", "golden", "scenes", scene)
+        entry = {"config": "%s levels %d/%d/%d (%d^3 voxels)" % (("Design2" if scene == "design2" else scene,) + levels + (1 << levels[2],))}
+        entry["export_roofline"] = export_roofline(scene, levels[2])
+        for key, extra in ((("warm_jit_cache", []), ("cold_jit", ["--cold-jit"])) if scene == "design2" else (("fresh_process", []),)):
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "export_from_disk.py"), "--scene-dir", d, "--levels"]
                                + [str(v) for v in levels] + extra, capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
@@ -233,7 +236,7 @@ def export_wall_clock(ev=None):
             entry.setdefault("ply_bytes", j["ply_bytes"])
             entry[key] = {k: j[k] for k in ("disk_to_files_s", "with_context_s", "create_context_s", "read_files_and_load_scene_s",
                                             "first_export_s", "steady_export_s", "load_scene_ms")}
-        entry["seconds"] = entry.get("warm_jit_cache", {}).get("disk_to_files_s")
+        entry["seconds"] = entry.get("warm_jit_cache", entry.get("fresh_process", {})).get("disk_to_files_s")
         out.append(entry)
     return out
 
@@ -309,6 +312,50 @@ def design2_sweeps(device):
         out[key] = dict(t, lattice_points=n1 ** 3, numerics="exact")
     ev.close()
     return out
+
+
+def many_object_sweeps(device):
+    """N=1 only, outside the timed region: BASELINE config 5's scenes (256 standard brushes: flat and grouped; the reference
+    cannot even load them, DrawPane.h:14-15) and a 128-brush scene of the design's own OpenCL brushes, swept densely at
+    512^3 -- kernel time of the fused and of the SDF-only sweep, fraction of the HBM peak, and the VALU issue rate against
+    the fixed ceiling (instruction counts per lattice point from the committed PMC profile of the same workload)."""
+    from designcsg_amd.evaluator import Evaluator
+    out = {}
+    for key in ("flat256_512", "grouped256_512", "userbrush128_512"):
+        scene, level, center, diameter = WORKLOADS[key]
+        ev = Evaluator(device)
+        assert ev.build_from_dir(os.path.join(ROOT, "tests", "golden", "scenes", scene))[0] == 0
+        k = ev.scene_info()["interpreter"]
+        res = 1 << level
+        t = time_sweeps(ev, center, diameter, res, reps=3, settle_s=0.05)
+        for form, kern in (("fused", KERNEL_VARIANT[k]), ("sdf_only", SDF_ONLY_KERNEL[k])):
+            t[form]["kernel"] = kern
+            p = profiled_valu_per_point(kern, scene)
+            if p:
+                t[form]["valu_issue"] = valu_issue(t[form]["kernel_ms"], (res + 1) ** 3, p[0], p[1])
+        out[key] = dict(t, lattice_points=(res + 1) ** 3, numerics="exact", objects=ev.scene_info()["objects"])
+        ev.close()
+    return out
+
+
+def export_roofline(scene, grid_level):
+    """Where an export's GPU time goes, from the newest committed rocprofv3 summary of that export
+    (profiles/r*_export_<scene>_<size>.json, written by profiles/summarise_export.py from kernel-trace and PMC passes of
+    tools/bench_export.py): the dominant kernel with its share, its VALU issue fraction and its HBM fraction."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_export_%s_%d.json" % (scene, 1 << grid_level))))
+    if not files:
+        return None
+    j = json.load(open(files[-1]))
+    k = j["dominant_kernel"]
+    o = j["kernels"][k]
+    top = sorted(j["kernels"].items(), key=lambda kv: -kv[1]["ms_per_export_settled_median"])[:4]
+    return {"source": "profiles/" + os.path.basename(files[-1]), "gpu_ms_per_export_settled": j["gpu_ms_per_export_settled"],
+            "dominant_kernel": k, "share_of_export_gpu_time": o["share_of_export_gpu_time"], "kernel_ms": o["ms_per_export_settled_median"],
+            "bound": "valu", "frac": o.get("valu_frac_of_ceiling"), "valu_per_SIMD_cycle": o.get("valu_per_SIMD_cycle"),
+            "hbm_frac": o.get("hbm_frac_of_peak"),
+            "kernels": {n: {"ms": v["ms_per_export_settled_median"], "valu_frac": v.get("valu_frac_of_ceiling"), "hbm_frac": v.get("hbm_frac_of_peak")}
+                        for n, v in top}}
 
 
 def main():
@@ -620,6 +667,7 @@ def main():
         if world == 1 and not args.no_secondary:
             out["secondary_sweeps"] = secondary_sweeps(scene_dir, local_rank, center, diameter, res)
             out["secondary_sweeps"].update(design2_sweeps(local_rank))
+            out["secondary_sweeps"].update(many_object_sweeps(local_rank))
         if world == 1 and not args.no_export:
             out["export_wall_clock"] = export_wall_clock()
         if world == 1 and not args.no_cpu_baseline:

@@ -18,6 +18,7 @@ EXPORT_SPARSE_NORMALS = 2
 EXPORT_INDEXED_PLY = 4     # opt-in writers beyond the reference's, include/dcsg.h
 EXPORT_STL_NORMALS = 8
 EXPORT_DENSE_SWEEP = 16
+EXPORT_EQUAL_SLABS = 64   # equal Z slabs instead of the work-balanced cuts (dcsg_export_slab / _multi)
 EXPORT_RETOPO = 32        # opt-in intended-semantics retopologize between mesher and projection
 
 
@@ -44,7 +45,7 @@ class ExportStats(C.Structure):
                 ("t_bbox", C.c_double), ("t_sweep", C.c_double), ("t_mesh", C.c_double),
                 ("t_project", C.c_double), ("t_download", C.c_double), ("t_write_stl", C.c_double),
                 ("t_write_ply", C.c_double), ("t_total", C.c_double), ("sweep_kernel_ms", C.c_double),
-                ("swept_points", C.c_uint64), ("swept_nodes", C.c_uint64)]
+                ("swept_points", C.c_uint64), ("swept_nodes", C.c_uint64), ("slab_z_lo", C.c_int32), ("slab_z_hi", C.c_int32)]
 
 
 # name -> (restype, argtypes); every prototype of include/dcsg.h

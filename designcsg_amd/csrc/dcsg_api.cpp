@@ -115,6 +115,9 @@ struct dcsg_ctx {
     bool cells_valid = false;
     double cells_built_ms = 0;  // host-side time spent building cells of the loaded scene so far (launch to completion)
     uint64_t cell_entries = 0, cells_built = 0;
+    // stage A's by-product for the Z-slab cuts: probes with |sdf| < one probe spacing per probe plane z = half_neg + cd (k - 128)
+    uint32_t probe_z_hist[256] = {};
+    float probe_cd = 0, probe_half_neg = 0;
     uint64_t n_tris = 0;
     uint64_t last_unique_vertices = 0;  // distinct positions projected by the last dcsg_project_triangles
     void* h_pinned = nullptr;  // host staging for triangle downloads
@@ -335,12 +338,24 @@ bool plan_scene_module(const Scene& s, const char* scene_cl, ModulePlan& p, std:
     const char* env_spec = getenv("DCSG_SPECIALISE");  // max object evaluations to specialise; 0 disables
     int spec_limit = env_spec ? atoi(env_spec) : 48;
     p.specialise = s.n_stack_prog > 0 && n_evals <= spec_limit && !getenv("DCSG_FORCE_VARIANT");  // A/B runs of the interpreters
+    // Larger programs of the design's OWN brushes (arbitrary OpenCL C is the norm: scenecompiler.py:227-241) are specialised
+    // too, in the THREADED form (csrc/specialise.cpp: emit_threaded_prelude): the program as a chain of calls of per-brush
+    // functions with the objects' constants in a table -- a few instructions per object, so the compile time stays that of
+    // a small scene, and nothing is decoded at run time.  Scenes of the standard brushes alone take the tile-culling kernels
+    // instead (they skip most of the objects; this would evaluate all of them).
+    const char* env_thr = getenv("DCSG_SPECIALISE_THREADED");  // max object evaluations for the threaded form; 0 disables
+    const int threaded_limit = env_thr ? atoi(env_thr) : 1024;
+    bool threaded = false;
+    if (!p.specialise && s.n_stack_prog > 0 && !builtin_only && n_evals <= threaded_limit && spec_limit > 0 && !getenv("DCSG_FORCE_VARIANT")) {
+        p.specialise = true;
+        threaded = true;
+    }
     p.needs_jit = !(builtin_only && !p.specialise) || relaxed;  // the relaxed arithmetic exists as a scene module only
     p.light = builtin_only && n_evals <= 4;
     if (p.needs_jit) {
         if (builtin_only) p.cl = builtin_scene_cl();
         p.null0 = builtin_only || scene_cl_null_brush_is_const(p.cl);
-        p.extra = specialised_source(s, p.null0, p.specialise, builtin_only && !getenv("DCSG_NO_SIMPLIFY"));
+        p.extra = specialised_source(s, p.null0, p.specialise, builtin_only && !getenv("DCSG_NO_SIMPLIFY"), threaded);
     }
     return true;
 }
@@ -997,7 +1012,8 @@ int dcsg_estimate_bounding_box(dcsg_ctx* c, float bb_half, float center[3], floa
     volatile float half_neg = -cd / 2;       // v3f(-cube_diameter / 2)
     double bb_eps = (double)((float)bb_half / R) * 1.0;  // BB_EPSILON
     if ((r = ensure(c, c->d_small, 4096))) return r;
-    int seed[12] = {1 << 20, 1 << 20, 1 << 20, -(1 << 20), -(1 << 20), -(1 << 20), 0, 0, 0, 0, 0, 0};
+    // [0..5] min / max indices, [8..9] interior count, [16..271] probes near the surface per probe plane in z
+    int seed[16 + 256] = {1 << 20, 1 << 20, 1 << 20, -(1 << 20), -(1 << 20), -(1 << 20)};
     HIPCHK(c, hipMemcpyAsync(c->d_small.p, seed, sizeof(seed), hipMemcpyHostToDevice, c->stream));
     const void* blob = c->d_blob.p;
     int nv = c->scene.blob_vec4();
@@ -1006,9 +1022,12 @@ int dcsg_estimate_bounding_box(dcsg_ctx* c, float bb_half, float center[3], floa
     void* args[] = {(void*)&blob, &nv, &cdv, &hnv, &bb_eps, (void*)&res_ptr};
     if ((r = launch(c, c->k->bbox[c->variant], (unsigned)c->n_cu * 16u, DCSG_BLOCK, c->scene.lds_bytes(), c->stream, args)))
         return r;
-    int out[12];
+    int out[16 + 256];
     HIPCHK(c, hipMemcpyAsync(out, c->d_small.p, sizeof(out), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 256; k++) c->probe_z_hist[k] = (uint32_t)out[16 + k];
+    c->probe_cd = cd;
+    c->probe_half_neg = half_neg;
     uint64_t cnt;
     memcpy(&cnt, &out[8], 8);
     float mn[3] = {0.0f, 0.0f, 0.0f}, mx[3] = {0.0f, 0.0f, 0.0f};  // initialised to 0.0, :688-693
@@ -2186,6 +2205,57 @@ int dcsg_expand_lookup_table(const char* txt, uint8_t table[4096], int* total)
 
 namespace {
 
+// Work-balanced Z slabs.  Where the work of an export is follows the surface: triangles, alive octree nodes, vertices to
+// project.  Stage A has just counted, per probe plane in z, the probes within one probe spacing of the surface -- a shell
+// whose volume per plane is proportional to the surface area crossing it, whatever its orientation -- and every rank holds
+// the same 256 integers (same kernel, same scene: no communication).  The N - 1 cut planes put an N-th of that count into
+// each slab, snapped to node boundaries of the sweep level (a node of that level must not straddle slabs) with at least
+// one node per slab; with an empty histogram the equal slabs stay.
+void slab_cut_planes(const dcsg_ctx* c, const dcsg_export_config& cfg, float center_z, float diameter, int rank, int world, int& z_lo, int& z_hi)
+{
+    const int res = 1 << cfg.grid_level;
+    const int sweep_level = cfg.min_level > 2 ? cfg.min_level : 2;
+    const int level = sweep_level <= cfg.grid_level ? sweep_level : cfg.grid_level;
+    const int node = res >> level;       // lattice planes per node of the sweep level
+    const int n_nodes = 1 << level;      // candidate cut planes: node * k
+    if (n_nodes < world || node < 1) return;
+    // work per node layer: the probe planes' counts spread over the lattice planes they cover
+    std::vector<double> layer((size_t)n_nodes, 0.0);
+    const double z0 = (double)center_z - 0.5 * (double)diameter, step = (double)diameter / res;
+    double total = 0;
+    for (int k = 0; k < 256; k++) {
+        if (!c->probe_z_hist[k]) continue;
+        const double z = (double)c->probe_half_neg + (double)c->probe_cd * (k - 128);
+        double f = (z - z0) / step / node;  // node layer of the probe plane
+        int l = (int)std::floor(f);
+        l = l < 0 ? 0 : (l >= n_nodes ? n_nodes - 1 : l);
+        layer[(size_t)l] += c->probe_z_hist[k];
+        total += c->probe_z_hist[k];
+    }
+    if (!(total > 0)) return;
+    // every layer also carries a small constant (an empty slab still costs its launches): 2 % of the mean
+    const double floor_w = 0.02 * total / n_nodes;
+    for (auto& w : layer) w += floor_w;
+    total += floor_w * n_nodes;
+    std::vector<int> cut((size_t)world + 1, 0);
+    cut[(size_t)world] = n_nodes;
+    double acc = 0;
+    int k = 1;
+    for (int l = 0; l < n_nodes && k < world; l++) {
+        acc += layer[(size_t)l];
+        // the cut after layer l when the running sum passes k / world of the total; keep room for the slabs still to come
+        while (k < world && acc >= total * k / world) {
+            int at = l + 1;
+            at = at < cut[(size_t)k - 1] + 1 ? cut[(size_t)k - 1] + 1 : at;
+            at = at > n_nodes - (world - k) ? n_nodes - (world - k) : at;
+            cut[(size_t)k++] = at;
+        }
+    }
+    for (; k < world; k++) cut[(size_t)k] = std::max(cut[(size_t)k - 1] + 1, n_nodes - (world - k));
+    z_lo = cut[(size_t)rank] * node;
+    z_hi = cut[(size_t)rank + 1] * node;
+}
+
 // Stages A .. projection of the export for Z slab `rank` of `world` (world = 1: the whole box).  Rank r owns the octree
 // nodes whose lowest lattice plane lies in [r res/world, (r+1) res/world); coarse nodes that straddle
 // slabs are classified by every rank from on-demand samples.  The lattice planes a slab's nodes read, including the
@@ -2210,7 +2280,10 @@ int export_mesh_stage(dcsg_ctx* c, const dcsg_export_config& cfg, int rank, int 
     const int res = 1 << cfg.grid_level;
     if (world < 1 || rank < 0 || rank >= world || res % world != 0)
         return fail(c, DCSG_ERR_INVALID, "the lattice does not split into that many equal Z slabs");
-    const int z_own_lo = rank * (res / world), z_own_hi = (rank + 1) * (res / world);
+    int z_own_lo = rank * (res / world), z_own_hi = (rank + 1) * (res / world);
+    if (world > 1 && !(flags & DCSG_EXPORT_EQUAL_SLABS)) slab_cut_planes(c, cfg, st.box_center[2], diameter, rank, world, z_own_lo, z_own_hi);
+    st.slab_z_lo = z_own_lo;
+    st.slab_z_hi = z_own_hi;
     const size_t n1 = (size_t)res + 1, plane = n1 * n1, n_pts = n1 * plane;
     const size_t slab_pts = (size_t)(z_own_hi - z_own_lo + 1) * plane;  // own planes + the shared upper one
     st.lattice_points = n_pts;

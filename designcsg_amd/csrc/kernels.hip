@@ -175,6 +175,9 @@ extern "C" __device__ float dcsg_spec_eval1(float x, float y, float z);
 // leave out terms with a zero coefficient, which is exact for finite coordinates only -- specialise.cpp)
 extern "C" __device__ float dcsg_spec_eval1x(float x, float y, float z);
 extern "C" __device__ int dcsg_spec_small();  // 1: few objects, row-invariant stencil terms may stay in registers
+extern "C" __device__ int dcsg_spec_threaded();  // 1: the evaluation is a chain of out-of-line calls (large programs)
+typedef float dcsg_cl_float4 __attribute__((ext_vector_type(4)));
+extern "C" __device__ dcsg_cl_float4 dcsg_spec_eval4(dcsg_cl_float4 px, dcsg_cl_float4 py, dcsg_cl_float4 pz);  // threaded form: four points
 #define DCSG_HAVE_SPEC 1
 #endif
 #else
@@ -1331,6 +1334,31 @@ __device__ __forceinline__ void dcsg_sweep_body(const uint4* __restrict__ blob, 
             continue;
         }
 #ifdef DCSG_HAVE_SPEC
+        // Threaded per-scene code (large programs: a chain of calls, one per object), SDF only: the run's four passes go
+        // through ONE chain (dcsg_spec_eval4) -- a call's cost (its
+        // constants' loads, the jump) is paid per 256 points instead of per 64, and four evaluations overlap.  Same
+        // arithmetic per point (the threaded form writes every term out: valid for any coordinate): same bits.
+        if (K < 0 && MODE == 1 && ax && left >= DCSG_RUN && dcsg_spec_threaded()) {
+            float px[4], py[4], pz[4];
+            if (ix0 + DCSG_RUN <= n1) {
+                const float y = dcsg_axis<XO>(L, ax, 1, iy0), z = dcsg_axis<XO>(L, ax, 2, plane0);
+                const float* xr = ax + ix0 + lane;
+#pragma unroll
+                for (int j = 0; j < 4; j++) px[j] = xr[64 * j], py[j] = y, pz[j] = z;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    DcsgWavePoint w = dcsg_wave_point<XO>(L, ax, ix0, iy0, plane0, lane);
+                    px[j] = w.x, py[j] = w.y, pz[j] = w.z;
+                    dcsg_wave_advance(n1, ix0, iy0, plane0);
+                }
+            }
+            const dcsg_cl_float4 vx = {px[0], px[1], px[2], px[3]}, vy = {py[0], py[1], py[2], py[3]}, vz = {pz[0], pz[1], pz[2], pz[3]};
+            const dcsg_cl_float4 o = dcsg_spec_eval4(vx, vy, vz);
+#pragma unroll
+            for (int j = 0; j < 4; j++) DCSG_STREAM_STORE(o[j], sdf_out + idx0 + lane + 64 * j);
+            continue;
+        }
         // Small scenes: passes that lie inside one lattice row share y and z, so everything the seven stencil evaluations
         // derive from those two alone is computed once for the passes of a row segment (loop-invariant code motion: same
         // operations, same bits), and the per-pass row tests disappear.
@@ -1579,6 +1607,29 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
         }
         dcsg_node_axes(L, i0, g.side, tab);
         const size_t base = ((size_t)i0[2] * n1 + (size_t)i0[1]) * n1 + (size_t)i0[0];
+#ifdef DCSG_HAVE_SPEC
+        if (K < 0 && sdf_out && !nrm_out && dcsg_spec_threaded()) {
+            // threaded per-scene code, SDF only: four of the node's points per lane through ONE chain of calls (dcsg_spec_eval4)
+            for (unsigned int p0 = 0; p0 < g.pts; p0 += 4u * DCSG_BLOCK) {
+                dcsg_cl_float4 vx, vy, vz;
+                size_t at[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned int p = p0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x;
+                    const unsigned int cp = p < g.pts ? p : g.pts - 1u;  // idle lanes evaluate the last point and store nothing
+                    unsigned int lx, ly, lz;
+                    dcsg_node_local(g, cp, lx, ly, lz);
+                    vx[j] = tab[lx], vy[j] = tab[DCSG_NODE_TAB + ly], vz[j] = tab[2 * DCSG_NODE_TAB + lz];
+                    at[j] = base + ((size_t)lz * n1 + ly) * n1 + lx;
+                }
+                const dcsg_cl_float4 o = dcsg_spec_eval4(vx, vy, vz);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (p0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x < g.pts) sdf_out[at[j]] = o[j];
+            }
+            continue;
+        }
+#endif
         for (unsigned int p = threadIdx.x; p < g.pts; p += DCSG_BLOCK) {
             unsigned int lx, ly, lz;
             dcsg_node_local(g, p, lx, ly, lz);
@@ -1694,7 +1745,11 @@ DCSG_EVAL_KERNEL(dcsg_eval_points_sp, -1)
 // Stage A's reduction: wave min / max / sum, one combine per block through LDS, then at most seven atomics per
 // block -- and none from blocks that saw no interior point (most of the probe cube).  Same-address atomics
 // serialise in L2: issued per wave they cost more than the 16.7 M evaluations (1.34 ms -> see DESIGN.md).
-__device__ __forceinline__ void dcsg_bbox_commit(int (&mn)[3], int (&mx)[3], unsigned int cnt, int* __restrict__ result)
+// zh: the block's histogram over the 256 probe planes in z of the probes NEAR the surface (|sdf| < one probe spacing), added
+// to result[16 .. 271]: what a Z-slab export balances its cuts on (work follows the surface, and every rank computes the
+// same integers without talking to anyone).
+__device__ __forceinline__ void dcsg_bbox_commit(int (&mn)[3], int (&mx)[3], unsigned int cnt, int* __restrict__ result,
+                                                 unsigned int* zh)
 {
     __shared__ int part[DCSG_BLOCK / DCSG_WAVE][8];
     for (int k = 0; k < 3; k++) {
@@ -1728,30 +1783,34 @@ __device__ __forceinline__ void dcsg_bbox_commit(int (&mn)[3], int (&mx)[3], uns
             atomicAdd(reinterpret_cast<unsigned long long*>(result + 8), (unsigned long long)total);
         }
     }
+    // (the barrier above also orders every thread's zh updates before these reads)
+    if (zh[threadIdx.x]) atomicAdd(reinterpret_cast<unsigned int*>(result) + 16 + threadIdx.x, zh[threadIdx.x]);
 }
+#define DCSG_BBOX_ZHIST_DECL                    \
+    __shared__ unsigned int zh[DCSG_BLOCK];     \
+    zh[threadIdx.x] = 0u;                       \
+    __syncthreads();
 
 template <int K>
 __device__ __forceinline__ void dcsg_bbox_body(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg,
                                                double bb_eps, int* __restrict__ result)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    DCSG_BBOX_ZHIST_DECL
     const unsigned int total = 256u * 256u * 256u;
     int mn[3] = {1 << 20, 1 << 20, 1 << 20};
     int mx[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
     unsigned int cnt = 0;
-    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < total; i += gridDim.x * DCSG_BLOCK) {
-        int iz = (int)(i & 255u) - 128;
-        int iy = (int)((i >> 8) & 255u) - 128;
-        int ix = (int)(i >> 16) - 128;
-        float x = half_neg + cd * (float)ix;
-        float y = half_neg + cd * (float)iy;
-        float z = half_neg + cd * (float)iz;
-        float v, u0, u1, u2;
-        if (K == 0) v = dcsg_primary_sdf(s, x, y, z);
-#ifdef DCSG_HAVE_SPEC
-        else if (K < 0) v = dcsg_spec_eval1(x, y, z);
-#endif
-        else dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, true, false, v, u0, u1, u2);
+    auto probe = [&](unsigned int i, float& x, float& y, float& z, int& ix, int& iy, int& iz) {
+        iz = (int)(i & 255u) - 128;
+        iy = (int)((i >> 8) & 255u) - 128;
+        ix = (int)(i >> 16) - 128;
+        x = half_neg + cd * (float)ix;
+        y = half_neg + cd * (float)iy;
+        z = half_neg + cd * (float)iz;
+    };
+    auto account = [&](float v, int ix, int iy, int iz) {
+        if ((double)__builtin_fabsf(v) < bb_eps) atomicAdd(&zh[iz + 128], 1u);
         if ((double)v < bb_eps) {  // "p.second < BB_EPSILON", float vs double
             cnt++;
             mn[0] = ix < mn[0] ? ix : mn[0];
@@ -1761,8 +1820,44 @@ __device__ __forceinline__ void dcsg_bbox_body(const uint4* __restrict__ blob, i
             mn[2] = iz < mn[2] ? iz : mn[2];
             mx[2] = iz > mx[2] ? iz : mx[2];
         }
+    };
+#ifdef DCSG_HAVE_SPEC
+    if (K < 0 && dcsg_spec_threaded()) {
+        // threaded per-scene code: four probes per lane through one chain of calls (the launch's grid is a power of two, so
+        // the strided loop covers the 2^24 probes in whole groups of four)
+        const unsigned int stride = gridDim.x * DCSG_BLOCK;
+        if (total % (4u * stride) == 0u) {
+            for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < total; i += 4u * stride) {
+                dcsg_cl_float4 vx, vy, vz;
+                int jx[4], jy[4], jz[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float x, y, z;
+                    probe(i + (unsigned int)j * stride, x, y, z, jx[j], jy[j], jz[j]);
+                    vx[j] = x, vy[j] = y, vz[j] = z;
+                }
+                const dcsg_cl_float4 o = dcsg_spec_eval4(vx, vy, vz);
+#pragma unroll
+                for (int j = 0; j < 4; j++) account(o[j], jx[j], jy[j], jz[j]);
+            }
+            dcsg_bbox_commit(mn, mx, cnt, result, zh);
+            return;
+        }
     }
-    dcsg_bbox_commit(mn, mx, cnt, result);
+#endif
+    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < total; i += gridDim.x * DCSG_BLOCK) {
+        int ix, iy, iz;
+        float x, y, z;
+        probe(i, x, y, z, ix, iy, iz);
+        float v, u0, u1, u2;
+        if (K == 0) v = dcsg_primary_sdf(s, x, y, z);
+#ifdef DCSG_HAVE_SPEC
+        else if (K < 0) v = dcsg_spec_eval1(x, y, z);
+#endif
+        else dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, true, false, v, u0, u1, u2);
+        account(v, ix, iy, iz);
+    }
+    dcsg_bbox_commit(mn, mx, cnt, result, zh);
 }
 
 #define DCSG_BBOX_KERNEL(NAME, K)                                                                                   \
@@ -2447,6 +2542,7 @@ extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, double bb_eps, int* __restrict__ result)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    DCSG_BBOX_ZHIST_DECL
     unsigned short* list = dcsg_wave_list(s, n_vec4);
     const unsigned int total = 256u * 256u * 256u;  // a multiple of the block size: every lane is valid
     int mn[3] = {1 << 20, 1 << 20, 1 << 20};
@@ -2464,6 +2560,7 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
         int n_list = dcsg_build_active_list(s, true, x, y, z, 0.0f, list, 0.0f, unused);
         float v, u0, u1, u2;
         dcsg_stencil<4>(s, x, y, z, true, false, v, u0, u1, u2, list, n_list);
+        if ((double)__builtin_fabsf(v) < bb_eps) atomicAdd(&zh[iz + 128], 1u);
         if ((double)v < bb_eps) {
             cnt++;
             mn[0] = ix < mn[0] ? ix : mn[0];
@@ -2474,7 +2571,7 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
             mx[2] = iz > mx[2] ? iz : mx[2];
         }
     }
-    dcsg_bbox_commit(mn, mx, cnt, result);
+    dcsg_bbox_commit(mn, mx, cnt, result, zh);
 }
 
 // Node-wise sweep with tile culling: the node's box is the tile.

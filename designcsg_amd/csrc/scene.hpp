@@ -63,7 +63,8 @@ float angle_threshold_to_q_star(float threshold);
 
 // csrc/specialise.cpp
 // simplify: the scene uses only the five standard brushes (see specialise.cpp for what that licenses)
-std::string specialised_source(const Scene& s, bool null_brush_const, bool enable, bool simplify);
+// threaded: object evaluations as calls of per-brush functions (large programs, csrc/specialise.cpp: emit_threaded_prelude)
+std::string specialised_source(const Scene& s, bool null_brush_const, bool enable, bool simplify, bool threaded = false);
 const char* builtin_scene_cl();
 
 uint64_t fnv1a64(const void* data, size_t n, uint64_t seed);

@@ -22,8 +22,11 @@ static std::string hexf(float f)
     return buf;
 }
 
-// N stencil points passed as float8 lanes (N = 7) or one point (N = 1)
-static void emit_function(const Scene& s, bool null_brush_const, int N, bool simplify, const char* name1, std::string& out)
+// N stencil points passed as float8 lanes (N = 7) or one point (N = 1).
+// threaded: every object evaluation is a CALL of an out-of-line function of its brush (emit_threaded_prelude) with a pointer
+// to the object's constants, instead of the transform and the brush written out in place.
+static void emit_function(const Scene& s, bool null_brush_const, int N, bool simplify, const char* name1, std::string& out,
+                          bool threaded = false)
 {
     enum {
         PUSH = 32, ACC_MIN = 33, ACC_MAX = 34, ACC_NEGMAX = 35, POP_MIN = 36, POP_MAX = 37, POP_NEGMAX = 38, EXPORT_TOP = 39,
@@ -39,9 +42,12 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
     // always_inline: whether the evaluation is inlined into a kernel must not depend on how many kernels of the module
     // call it (the stencil points share sub-expressions with their caller only when it is)
     const bool exact_copy = std::string(name1) == "dcsg_spec_eval1x";  // rare path, kept out of line by its caller
-    const char* inl = exact_copy ? "" : "__attribute__((always_inline)) ";
+    // (the threaded form is a long chain of calls: one copy per module, called)
+    const char* inl = threaded ? "__attribute__((noinline)) " : (exact_copy ? "" : "__attribute__((always_inline)) ");
     if (N == 7)
         out += std::string(inl) + "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){\n";
+    else if (N == 4)
+        out += std::string(inl) + "float4 dcsg_spec_eval4(float4 px, float4 py, float4 pz){\n";
     else
         out += std::string(inl) + "float " + name1 + "(float x, float y, float z){\n";
     auto X = [&](int k) { return N > 1 ? std::string("px.s") + hexdigit[k] : std::string("x"); };
@@ -75,6 +81,13 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
             out += "  {\n";
             if (brush == 0 && null_brush_const) {
                 for (int k = 0; k < N; k++) P("    const float r%d = (float)MAX_DISTANCE;\n", k);
+            } else if (threaded) {
+                if (N > 1) {
+                    P("    const float%d rr = dcsg_spec_b%d_%d(px, py, pz, dcsg_spec_T + %d);\n", N == 7 ? 8 : 4, brush, N, 12 * obj);
+                    for (int k = 0; k < N; k++) P("    const float r%d = rr.s%d;\n", k, k);
+                } else {
+                    P("    const float r0 = dcsg_spec_b%d_1(x, y, z, dcsg_spec_T + %d);\n", brush, 12 * obj);
+                }
             } else {
                 const float* o = &s.pos[3 * obj];
                 const float* r = &s.right[3 * obj];
@@ -157,26 +170,92 @@ static void emit_function(const Scene& s, bool null_brush_const, int N, bool sim
     }
     if (N == 7)
         out += "  return (float8)(o0, o1, o2, o3, o4, o5, o6, 0.0f);\n}\n";
+    else if (N == 4)
+        out += "  return (float4)(o0, o1, o2, o3);\n}\n";
     else
         out += "  return o0;\n}\n";
+}
+
+// The threaded form's constants and brush functions: the objects' twelve numbers each in a __constant table (exact
+// hexadecimal literals), and per brush in use one out-of-line function for seven points and one for a single point that
+// read an object's numbers through a pointer (uniform: scalar loads), transform the points exactly as the interpreters do
+// (k2.cl:105-111, every term written out) and evaluate the brush.  The program itself then is a chain of calls and joins:
+// a few instructions per object whatever the brushes cost, so the code a large scene adds to a module -- and the time to
+// compile it -- stays small, while nothing is decoded at run time.  Same operations in the same order: same bits.
+static void emit_threaded_prelude(const Scene& s, bool null_brush_const, std::string& out)
+{
+    char line[256];
+    out += "__constant float dcsg_spec_T[] = {\n";
+    for (int o = 0; o < s.n_objects; o++) {
+        const float* v[4] = {&s.pos[3 * o], &s.right[3 * o], &s.up[3 * o], &s.fwd[3 * o]};
+        out += "  ";
+        for (auto p : v)
+            for (int q = 0; q < 3; q++) out += hexf(p[q]) + ", ";
+        out += "\n";
+    }
+    out += "  0.0f};\n";
+    bool used[256] = {};
+    for (int c = 0; c < s.n_stack_prog; c++) {
+        const int op = s.stack_prog[4 * c], brush = s.stack_prog[4 * c + 1] & 0xff;
+        if (((op >= 32 && op <= 35) || (op >= 41 && op <= 43)) && !(brush == 0 && null_brush_const)) used[brush] = true;
+    }
+    const char* load = "  const float ox=T[0], oy=T[1], oz=T[2], rx=T[3], ry=T[4], rz=T[5], ux=T[6], uy=T[7], uz=T[8], fx=T[9], fy=T[10], fz=T[11];\n";
+    for (int b = 0; b < 256; b++) {
+        if (!used[b]) continue;
+        for (int n : {7, 4}) {
+            const int w = n == 7 ? 8 : 4;
+            snprintf(line, sizeof(line), "__attribute__((noinline)) float%d dcsg_spec_b%d_%d(float%d px, float%d py, float%d pz, __constant float* T){\n", w,
+                     b, n, w, w, w);
+            out += line;
+            out += load;
+            snprintf(line, sizeof(line), "  float%d r = (float%d)(0.0f);\n", w, w);
+            out += line;
+            for (int k = 0; k < n; k++) {
+                snprintf(line, sizeof(line),
+                         "  { const float dx = px.s%d - ox, dy = py.s%d - oy, dz = pz.s%d - oz;\n"
+                         "    r.s%d = sdf_bank((float3)(dx*rx + dy*ry + dz*rz, dx*ux + dy*uy + dz*uz, dx*fx + dy*fy + dz*fz), (unsigned char)%d); }\n",
+                         k, k, k, k, b);
+                out += line;
+            }
+            out += "  return r;\n}\n";
+        }
+        snprintf(line, sizeof(line), "__attribute__((noinline)) float dcsg_spec_b%d_1(float x, float y, float z, __constant float* T){\n", b);
+        out += line;
+        out += load;
+        snprintf(line, sizeof(line),
+                 "  const float dx = x - ox, dy = y - oy, dz = z - oz;\n"
+                 "  return sdf_bank((float3)(dx*rx + dy*ry + dz*rz, dx*ux + dy*uy + dz*uz, dx*fx + dy*fy + dz*fz), (unsigned char)%d);\n}\n", b);
+        out += line;
+    }
 }
 
 // OpenCL C for dcsg_spec_eval7 / dcsg_spec_eval1.  With `enable` false (or a program that is not
 // stack-disciplined) it emits stubs, which only satisfy the linker: the host never selects the
 // specialised kernels for such a scene.
-std::string specialised_source(const Scene& s, bool null_brush_const, bool enable, bool simplify)
+std::string specialised_source(const Scene& s, bool null_brush_const, bool enable, bool simplify, bool threaded)
 {
     std::string out = "\n/* ---- generated by csrc/specialise.cpp ---- */\n";
     if (!enable || s.n_stack_prog == 0) {
         out += "float8 dcsg_spec_eval7(float8 px, float8 py, float8 pz){ return (float8)(0.0f); }\n";
+        out += "float4 dcsg_spec_eval4(float4 px, float4 py, float4 pz){ return (float4)(0.0f); }\n";
         out += "float dcsg_spec_eval1(float x, float y, float z){ return 0.0f; }\n";
         out += "float dcsg_spec_eval1x(float x, float y, float z){ return 0.0f; }\n";
         out += "int dcsg_spec_small(void){ return 0; }\n";
+        out += "int dcsg_spec_threaded(void){ return 0; }\n";
         return out;
     }
-    emit_function(s, null_brush_const, 7, simplify, "", out);
-    emit_function(s, null_brush_const, 1, simplify, "dcsg_spec_eval1", out);
-    emit_function(s, null_brush_const, 1, false, "dcsg_spec_eval1x", out);  // every term written out: any input
+    if (threaded) {  // large programs: calls instead of inline code (every term written out: eval1 serves any input)
+        emit_threaded_prelude(s, null_brush_const, out);
+        emit_function(s, null_brush_const, 7, false, "", out, true);
+        emit_function(s, null_brush_const, 4, false, "", out, true);   // four points: the SDF-only sweeps' runs
+        emit_function(s, null_brush_const, 1, false, "dcsg_spec_eval1", out, true);
+        emit_function(s, null_brush_const, 1, false, "dcsg_spec_eval1x", out, true);
+    } else {
+        emit_function(s, null_brush_const, 7, simplify, "", out);
+        emit_function(s, null_brush_const, 1, simplify, "dcsg_spec_eval1", out);
+        emit_function(s, null_brush_const, 1, false, "dcsg_spec_eval1x", out);  // every term written out: any input
+        out += "float4 dcsg_spec_eval4(float4 px, float4 py, float4 pz){ return (float4)(0.0f); }\n";  // threaded form only
+    }
     // dcsg_spec_small: the scene evaluates at most four objects, so the row-invariant part of its seven stencil
     // evaluations fits in registers and the sweep may keep it across the passes of a run (kernels.hip, dcsg_sweep_body)
     int evals = 0;
@@ -185,6 +264,8 @@ std::string specialised_source(const Scene& s, bool null_brush_const, bool enabl
         if (((op >= 32 && op <= 35) || (op >= 41 && op <= 43)) && !(brush == 0 && null_brush_const)) evals++;
     }
     out += std::string("__attribute__((always_inline)) int dcsg_spec_small(void){ return ") + (evals <= 4 ? "1" : "0") + "; }\n";
+    // dcsg_spec_threaded: the evaluation is a chain of calls -- the SDF-only sweeps then send four points through one chain
+    out += std::string("__attribute__((always_inline)) int dcsg_spec_threaded(void){ return ") + (threaded ? "1" : "0") + "; }\n";
     return out;
 }
 

@@ -243,10 +243,12 @@ class Evaluator:
         return st
 
 
-    def export_slab(self, export_config_txt, rank, world, dense_normals=False, dense_sweep=False):
-        """Z slab `rank` of `world` of the export, stages A .. projection; triangles stay on the device."""
+    def export_slab(self, export_config_txt, rank, world, dense_normals=False, dense_sweep=False, equal_slabs=False):
+        """Z slab `rank` of `world` of the export (work-balanced cut planes unless equal_slabs), stages A .. projection;
+        triangles stay on the device.  st.slab_z_lo / st.slab_z_hi: the lattice planes owned."""
         st = ExportStats()
-        flags = (_lib.EXPORT_DENSE_NORMALS if dense_normals else 0) | (_lib.EXPORT_DENSE_SWEEP if dense_sweep else 0)
+        flags = (_lib.EXPORT_DENSE_NORMALS if dense_normals else 0) | (_lib.EXPORT_DENSE_SWEEP if dense_sweep else 0) | \
+            (_lib.EXPORT_EQUAL_SLABS if equal_slabs else 0)
         self._ck(self._L.dcsg_export_slab(self._h, export_config_txt.encode(), int(rank), int(world), flags, C.byref(st)))
         return st
 

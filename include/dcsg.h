@@ -75,6 +75,8 @@ typedef struct dcsg_export_stats {
      * sweep (nodes x (2^(grid-min)+1)^3, shared faces counted per node) */
     uint64_t swept_points;
     uint64_t swept_nodes;      /* 0 for a dense sweep */
+    /* the lattice planes this export owned: [slab_z_lo, slab_z_hi) of 0 .. 2^gridLevel (the whole range unless dcsg_export_slab) */
+    int32_t slab_z_lo, slab_z_hi;
 } dcsg_export_stats;
 
 /* ---- life cycle ------------------------------------------------------------------- */
@@ -204,14 +206,18 @@ int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* 
 #define DCSG_EXPORT_DENSE_SWEEP 16u   /* sweep the whole lattice even where the node-wise sweep would do */
 #define DCSG_EXPORT_INDEXED_PLY 4u    /* ply_path gets dcsg_write_ply_indexed instead of the reference layout */
 #define DCSG_EXPORT_STL_NORMALS 8u    /* stl_path gets dcsg_write_stl_normals instead of zero normals */
+#define DCSG_EXPORT_EQUAL_SLABS 64u   /* dcsg_export_slab / _multi: equal Z slabs instead of the work-balanced cuts */
 #define DCSG_EXPORT_RETOPO 32u        /* run dcsg_retopologize between the mesher and the projection (default: identity);
                                          whole-mesh exports only: DCSG_ERR_INVALID from dcsg_export_slab / _multi with
                                          world > 1 (a slab sees only its own vertices, T-junctions on slab borders would stay) */
 int dcsg_export(dcsg_ctx* ctx, const char* export_config_txt, const char* stl_path, const char* ply_path,
                 unsigned flags, dcsg_export_stats* stats);
 
-/* Sharded export: Z slab `rank` of `world` equal slabs (world divides 2^gridLevel), stages A ..
- * projection, no files.  The rank owns the octree nodes whose lowest lattice plane lies in its slab; it evaluates every
+/* Sharded export: Z slab `rank` of `world` (world divides 2^gridLevel), stages A .. projection, no files.
+ * The cut planes are WORK-BALANCED by default: stage A counts, per probe plane in z, the probes near the surface (every rank
+ * the same integers, no communication), and the N - 1 cuts put an N-th of that count into each slab, on node boundaries of
+ * the sweep level; DCSG_EXPORT_EQUAL_SLABS restores equal slabs.  stats->slab_z_lo / _hi report the planes owned.
+ * The rank owns the octree nodes whose lowest lattice plane lies in its slab; it evaluates every
  * lattice value its nodes read itself (including the plane shared with the slab above), so no exchange is needed here.
  * One context per GPU: one process per GPU over torch.distributed (designcsg_amd/sharded.py), or one host thread per
  * context in a single process.  The union of the slabs' triangles is the triangle set of dcsg_export. */

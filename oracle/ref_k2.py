@@ -36,7 +36,7 @@ FLAVOURS = ("default", "strict")
 # global_state (its brushes write program-scope __global variables that a later call reads back: a data race as soon
 # as two work-items run at once, which is what a GPU does) and the smooth-join extension scenes (opcodes k2.cl's
 # switch ignores).
-SCENES = ("sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "prefabs", "const_table", "ad_table")
+SCENES = ("sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "prefabs", "const_table", "ad_table", "userbrush128")
 
 
 def hsaco_path(scene, flavour="strict"):

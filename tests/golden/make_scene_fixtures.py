@@ -41,6 +41,7 @@ DESIGNS = {
     "prefabs": os.path.join(OWN_DESIGNS, "prefabs.py"),
     "const_table": os.path.join(OWN_DESIGNS, "const_table.py"),
     "global_state": os.path.join(OWN_DESIGNS, "global_state.py"),
+    "userbrush128": os.path.join(OWN_DESIGNS, "userbrush128.py"),
 }
 FILES = ["scene.txt", "buildprocedure.txt", "scene.cl", "exportConfig.txt"]
 

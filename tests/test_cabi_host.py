@@ -12,7 +12,7 @@ import pytest
 from conftest import ROOT, TABLE, read_scene, scene_dir
 
 HEADER = os.path.join(ROOT, "include", "dcsg.h")
-ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table", "prefabs", "const_table", "global_state"]
+ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table", "prefabs", "const_table", "global_state", "userbrush128"]
 
 
 def declared_functions():

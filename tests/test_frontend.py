@@ -21,7 +21,7 @@ def run(script, workdir):
                    check=True, stdout=subprocess.DEVNULL)
 
 
-@pytest.mark.parametrize("name", ["sphere", "mixed_groups", "flat256", "grouped256", "ad_table", "const_table", "global_state"])
+@pytest.mark.parametrize("name", ["sphere", "mixed_groups", "flat256", "grouped256", "ad_table", "const_table", "global_state", "userbrush128"])
 def test_own_design_scripts_reproduce_reference_output(name, tmp_path):
     run(os.path.join(DESIGNS, name + ".py"), tmp_path)
     for f in FILES:

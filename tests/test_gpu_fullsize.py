@@ -170,6 +170,21 @@ def test_slab_exports_write_the_whole_mesh_into_one_file(ev, name, levels, world
     stats = [ev.export_slab(cfg_txt, r, world) for r in range(world)]
     counts = [int(st.triangles) for st in stats]
     assert sum(counts) == whole.triangles
+    # the cut planes: work-balanced by default (stage A's count of probes near the surface per z plane, the same integers on
+    # every rank), on node boundaries of the sweep level, tiling 0 .. res without gaps
+    res, node = 1 << levels[2], (1 << levels[2]) >> min(max(levels[0], 2), levels[2])
+    assert stats[0].slab_z_lo == 0 and stats[-1].slab_z_hi == res
+    assert all(stats[r].slab_z_hi == stats[r + 1].slab_z_lo for r in range(world - 1))
+    assert all(st.slab_z_hi > st.slab_z_lo for st in stats)
+    if (1 << min(max(levels[0], 2), levels[2])) >= world:     # otherwise (sweep level coarser than the slabs) the equal slabs stay
+        assert all(st.slab_z_lo % node == 0 for st in stats)
+    equal = [ev.export_slab(cfg_txt, r, world, equal_slabs=True) for r in range(world)]
+    assert [(st.slab_z_lo, st.slab_z_hi) for st in equal] == [(r * res // world, (r + 1) * res // world) for r in range(world)]
+    assert sum(int(st.triangles) for st in equal) == whole.triangles
+    if (name, levels, world) == ("design2", (7, 9, 10), 8):
+        # Design2 sits in the middle of its box: an equal eighth holds 1.77 x the mean, the balanced cuts stay under 1.3 x
+        assert max(int(st.triangles) for st in equal) > 1.7 * whole.triangles / world
+        assert max(counts) < 1.3 * whole.triangles / world, counts
     for f in ("culled", "subdivided", "leaves", "triangles"):
         assert [sum(int(getattr(st.mesh, f)[l]) for st in stats) for l in range(16)] == [int(v) for v in getattr(whole.mesh, f)], f
     if whole.swept_nodes and (1 << max(levels[0], 2)) >= world:

@@ -13,7 +13,7 @@ from conftest import ROOT, export_config_text, read_scene, scene_dir
 
 pytestmark = pytest.mark.gpu
 
-ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table", "prefabs", "const_table", "global_state",
+ALL_SCENES = ["sphere", "design1", "design2", "mixed_groups", "flat256", "grouped256", "ad_table", "prefabs", "const_table", "global_state", "userbrush128",
               "smooth_blobs", "smooth256"]   # the last two: smooth-join extension, parity vs the oracle only
 STL_TOL = 1e-5  # north_star: ".stl diff within 1e-5"
 
@@ -44,10 +44,11 @@ def sorted_tris(t):
 
 
 EXPECTED_STACK_DEPTH = {"sphere": 1, "design1": 1, "design2": 1, "flat256": 1, "mixed_groups": 2, "grouped256": 2,
-                        "ad_table": 1, "prefabs": 2, "const_table": 1, "global_state": 1, "smooth_blobs": 3, "smooth256": 2}
+                        "ad_table": 1, "prefabs": 2, "const_table": 1, "global_state": 1, "smooth_blobs": 3, "smooth256": 2, "userbrush128": 1}
 
 
-SPECIALISED = {"sphere", "design1", "design2", "mixed_groups", "ad_table", "prefabs", "const_table", "global_state", "smooth_blobs"}  # <= 48 object evaluations
+# <= 48 object evaluations: inline per-scene code; userbrush128 (128 evaluations of the design's own brushes): the threaded form
+SPECIALISED = {"sphere", "design1", "design2", "mixed_groups", "ad_table", "prefabs", "const_table", "global_state", "smooth_blobs", "userbrush128"}
 
 
 @pytest.mark.parametrize("interpreter", ["auto", "stack", "generic"])
@@ -323,7 +324,8 @@ def test_builtin_bank_equals_jit_bank(ev, oracle):
     assert np.array_equal(bits(a), bits(b))
 
 
-@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table", "const_table", "global_state", "smooth_blobs", "flat256", "grouped256", "smooth256"])
+@pytest.mark.parametrize("name", ["sphere", "design2", "mixed_groups", "ad_table", "const_table", "global_state", "smooth_blobs", "flat256", "grouped256", "smooth256",
+                                  "userbrush128"])
 def test_lattice_sweep_bit_exact(ev, oracle, name):
     load(ev, name)
     osc = oracle.Scene.from_dir(scene_dir(name))
@@ -482,7 +484,7 @@ GOLD_TRIS_128 = {  # levels 4/6/7, per-level triangle counts
 }
 
 
-@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups", "ad_table", "const_table", "global_state", "smooth_blobs"])
+@pytest.mark.parametrize("name", ["sphere", "design1", "design2", "mixed_groups", "ad_table", "const_table", "global_state", "smooth_blobs", "userbrush128"])
 @pytest.mark.parametrize("dense_normals", [False, True])
 def test_mesher_and_projection_bit_exact(ev, oracle, lookup_table, name, dense_normals, tmp_path):
     load(ev, name)
