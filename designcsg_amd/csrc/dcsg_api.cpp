@@ -104,6 +104,7 @@ struct dcsg_ctx {
     int numerics = 0;  // DCSG_NUMERICS_EXACT / _RELAXED for the scenes loaded from now on (dcsg_set_numerics)
     bool scene_relaxed = false;
     int variant = 0;  // index into Kernels::sweep[] etc., chosen from the scene's register count
+    int n_object_evals = 0;  // brush evaluations per evaluation of the scene (leaf steps of the stack program)
     Scene scene;
     std::vector<float> ad_host;
     std::vector<uint8_t> tri_table;
@@ -120,6 +121,9 @@ struct dcsg_ctx {
     float probe_cd = 0, probe_half_neg = 0;
     uint64_t n_tris = 0;
     uint64_t last_unique_vertices = 0;  // distinct positions projected by the last dcsg_project_triangles
+    // pinned host words for the small read-backs (counts, totals, the bounding-box words): a copy into pageable memory goes
+    // through the runtime's staging path and costs tens of microseconds more, a dozen times per export
+    unsigned char* h_words = nullptr;  // 8 KiB
     void* h_pinned = nullptr;  // host staging for triangle downloads
     size_t h_pinned_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -615,6 +619,7 @@ int dcsg_create(dcsg_ctx** out, int device_id)
     if (c->max_lds > 160 * 1024) c->max_lds = 160 * 1024;
     lap.mark("hip_runtime_and_device");
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipHostMalloc((void**)&c->h_words, 8192, hipHostMallocDefault));
     CK(hipEventCreate(&c->ev0));
     for (auto& pr : c->sweep_ev) {
         CK(hipEventCreate(&pr[0]));
@@ -674,6 +679,7 @@ void dcsg_destroy(dcsg_ctx* c)
                       &c->d_rt_keep, &c->d_rt_out, &c->d_cells, &c->d_cell_entries, &c->d_cell_want, &c->d_cell_words, &c->d_cell_work};
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->h_words) hipHostFree(c->h_words);
     join_rest_thread(c);
     if (c->scene_mod) hipModuleUnload(c->scene_mod);
     if (c->scene_mod_rest) hipModuleUnload(c->scene_mod_rest);
@@ -851,6 +857,7 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     {
         int n_evals = 0;
         for (int k = 0; k < c->scene.n_stack_prog; k++) n_evals += (c->scene.stack_prog[4 * k] <= 35 || (c->scene.stack_prog[4 * k] >= 41 && c->scene.stack_prog[4 * k] <= 43)) ? 1 : 0;
+        c->n_object_evals = n_evals;
         const char* env_cull = getenv("DCSG_CULL");
         int min_objects = env_cull ? atoi(env_cull) : 16;  // 0 disables
         if (!c->jit && c->scene.n_items > 0 && min_objects > 0 && n_evals >= min_objects) c->variant = 4;
@@ -1022,8 +1029,8 @@ int dcsg_estimate_bounding_box(dcsg_ctx* c, float bb_half, float center[3], floa
     void* args[] = {(void*)&blob, &nv, &cdv, &hnv, &bb_eps, (void*)&res_ptr};
     if ((r = launch(c, c->k->bbox[c->variant], (unsigned)c->n_cu * 16u, DCSG_BLOCK, c->scene.lds_bytes(), c->stream, args)))
         return r;
-    int out[16 + 256];
-    HIPCHK(c, hipMemcpyAsync(out, c->d_small.p, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    int* out = (int*)c->h_words;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_small.p, (16 + 256) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < 256; k++) c->probe_z_hist[k] = (uint32_t)out[16 + k];
     c->probe_cd = cd;
@@ -1171,7 +1178,7 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             HIPCHK(c, hipEventRecord(c->ev0, s));
             if ((r = launch(c, c->k->sweep_nodes[c->variant], n_nodes, DCSG_BLOCK, c->scene.lds_bytes(), s, args))) return r;
             HIPCHK(c, hipEventRecord(c->ev1, s));
-            unsigned swept = 0;
+            unsigned& swept = *(unsigned*)c->h_words;
             HIPCHK(c, hipMemcpyAsync(&swept, d_swept, sizeof(swept), hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
             float ms = 0;
@@ -1214,8 +1221,8 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             void* args[] = {(void*)&d_bs, &n_blocks, (void*)&d_totals};
             if ((r = launch(c, c->k->scan, 1, 1024, 0, s, args))) return r;
         }
-        unsigned totals[2];
-        HIPCHK(c, hipMemcpyAsync(totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost, s));
+        unsigned* totals = (unsigned*)c->h_words;
+        HIPCHK(c, hipMemcpyAsync(totals, d_totals, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         unsigned n_children = totals[0], n_new_tris = totals[1];
         if ((r = ensure(c, c->d_nodes[cur ^ 1], (size_t)(n_children ? n_children : 1) * 3 * sizeof(float)))) return r;
@@ -1236,8 +1243,8 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
         cur ^= 1;
         for (int k = 0; k < 3; k++) hd[k] = 0.5f * hd[k];
     }
-    unsigned long long ls[DCSG_MAX_LEVELS * 4];
-    HIPCHK(c, hipMemcpyAsync(ls, d_lstats, sizeof(ls), hipMemcpyDeviceToHost, s));
+    unsigned long long* ls = (unsigned long long*)c->h_words;
+    HIPCHK(c, hipMemcpyAsync(ls, d_lstats, DCSG_MAX_LEVELS * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     for (int l = 0; l < DCSG_MAX_LEVELS; l++) {
         st.culled[l] = ls[4 * l];
@@ -1313,7 +1320,7 @@ int ensure_cell_grid(dcsg_ctx* c, hipStream_t s)
 {
     if (c->cells_valid) return 0;
     const char* eg = getenv("DCSG_CELLS");
-    int g = eg ? atoi(eg) : 64;
+    int g = eg ? atoi(eg) : 128;  // measured 32 .. 256 on the 256-brush scenes at 512^3 and 1024^3: 128 is the fastest, cold and warm
     g = (g < 4 ? 4 : (g > 256 ? 256 : g)) & ~3;  // a coarse cell is 4 x 4 x 4 fine ones
     c->cell_grid = cell_grid_for(c->scene, g);
     const uint64_t n_cells = (uint64_t)g * g * g, n_coarse = n_cells / 64, n_all = n_cells + 1 + n_coarse;
@@ -1366,8 +1373,8 @@ int build_wanted_cells(dcsg_ctx* c, hipStream_t s)
         void* args[] = {(void*)&blob, &nv, (void*)&c->cell_grid, &cells, &entries, (void*)&counter, &cap, &want, &work};
         const unsigned blocks = (unsigned)std::min<uint64_t>((n_cells + 4) / 4, (uint64_t)c->n_cu * 12);
         if ((r = launch(c, c->kb.cells_build, blocks, DCSG_BLOCK, c->scene.lds_bytes(), s, args))) return r;
-        unsigned words[4] = {0, 0, 0, 0};
-        HIPCHK(c, hipMemcpyAsync(words, counter, sizeof(words), hipMemcpyDeviceToHost, s));
+        unsigned* words = (unsigned*)c->h_words;
+        HIPCHK(c, hipMemcpyAsync(words, counter, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         const unsigned used = words[0];
         c->cells_built = words[3];
@@ -1497,11 +1504,12 @@ int dedup_prepare(dcsg_ctx* c, hipStream_t s, Dedup& d, const unsigned* probe_bl
         void* args[] = {(void*)&bs, &n_blocks, (void*)&totals};
         if ((r = launch(c, c->k->scan, 1, 1024, 0, s, args))) return r;
     }
-    unsigned tot[2];
-    HIPCHK(c, hipMemcpyAsync(tot, totals, sizeof(tot), hipMemcpyDeviceToHost, s));
+    unsigned* tot = (unsigned*)c->h_words;  // pinned; the probes behind it (n_probe <= 8)
+    HIPCHK(c, hipMemcpyAsync(tot, totals, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     for (int k = 0; k < n_probe; k++)
-        HIPCHK(c, hipMemcpyAsync(&probe_out[k], bs + 2 * (size_t)probe_blocks[k], sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(tot + 2 + k, bs + 2 * (size_t)probe_blocks[k], sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    for (int k = 0; k < n_probe; k++) probe_out[k] = tot[2 + k];
     unsigned n_unique = tot[0];
     if ((r = ensure(c, c->d_dd_compact, (size_t)(n_unique ? n_unique : 1) * 3 * sizeof(float)))) return r;
     float* compact = (float*)c->d_dd_compact.p;
@@ -2426,7 +2434,11 @@ int project_download_write(dcsg_ctx* c, int steps, const char* stl_path, const c
     // Not for the tile-culling kernels: their projection is bound by the 50 dependent steps of a wave, not by throughput,
     // so a launch over a quarter of the vertices takes almost as long as one over all of them (flat256 1024^3: 41 ms in
     // 4 chunks against 15 ms in one).
-    if (K < 2 || T < 200000 || !reference_writers || !(stl_path || ply_path) || T * 3 > (1ull << 30) || c->variant == 4) return 1;
+    // ... and not for programs of many brush evaluations, for the same reason (userbrush128, 128 evaluations, 512^3: 33 ms in
+    // four chunks, 24 in two, 21 in one; Design2 1024^3: 15.9 / 14.9 / 18.4)
+    if (K < 2 || T < 200000 || !reference_writers || !(stl_path || ply_path) || T * 3 > (1ull << 30) || c->variant == 4 ||
+        (c->n_object_evals >= 32 && !env))
+        return 1;
     int r = need_scene(c);
     if (r) return r;
     const double t0 = now_s();

@@ -616,7 +616,7 @@ def test_cell_list_projection(ev, oracle, name, monkeypatch):
             assert same(t.cpu().numpy(), wants[which]), (name, "region", which)
             if which == 0:
                 built = ev.debug_cells()
-                assert built["grid"] == 64 and built["cells_built"] > 0
+                assert built["grid"] == 128 and built["cells_built"] > 0
                 ev.export(export_config_text(name, levels=(3, 5, 6), gd=2))
             else:
                 assert ev.debug_cells()["cells_built"] > built["cells_built"]

@@ -22,9 +22,10 @@ for name in (sys.argv[1:] or ("flat256", "design2")):
                 out = []
                 for r in range(world):
                     t0 = time.perf_counter(); st = ev.export_slab(cfg, r, world, equal_slabs=equal); t1 = time.perf_counter()
-                    out.append((round((t1 - t0) * 1e3, 2), int(st.triangles), (st.slab_z_lo, st.slab_z_hi)))
+                    out.append((round((t1 - t0) * 1e3, 2), int(st.triangles), (st.slab_z_lo, st.slab_z_hi),
+                                "A %.2f sweep %.2f mesh %.2f proj %.2f" % (st.t_bbox * 1e3, st.t_sweep * 1e3, st.t_mesh * 1e3, st.t_project * 1e3)))
                 if best is None or max(o[0] for o in out) < max(o[0] for o in best):
                     best = out
             print(name, "world", world, "equal" if equal else "balanced", "slowest rank %.2f ms of whole %.2f ms (x%.2f)" % (
-                max(o[0] for o in best), min(whole) * 1e3, min(whole) * 1e3 / max(o[0] for o in best)), "per rank (ms, triangles, planes):", best)
+                max(o[0] for o in best), min(whole) * 1e3, min(whole) * 1e3 / max(o[0] for o in best)), "per rank (ms, triangles, planes, stages):", best)
     ev.close()
