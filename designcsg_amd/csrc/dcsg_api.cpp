@@ -243,7 +243,7 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind, int part = 
         HIPCHK(c, hipModuleGetFunction(&k.sweep_f[4], mod, "dcsg_sweep_c4_f"));
         HIPCHK(c, hipModuleGetFunction(&k.sweep_nodes[4], mod, "dcsg_sweep_nodes_c4"));
         HIPCHK(c, hipModuleGetFunction(&k.bbox[4], mod, "dcsg_bbox_c4"));
-        HIPCHK(c, hipModuleGetFunction(&k.project[4], mod, "dcsg_project_c4"));
+        k.project[4] = nullptr;  // culling scenes project through the cell lists (project_cells)
         HIPCHK(c, hipModuleGetFunction(&k.cells_mark, mod, "dcsg_cells_mark"));
         HIPCHK(c, hipModuleGetFunction(&k.cells_collect, mod, "dcsg_cells_collect"));
         HIPCHK(c, hipModuleGetFunction(&k.cells_build, mod, "dcsg_cells_build"));
@@ -1446,7 +1446,7 @@ int dcsg_project_vertices_device(dcsg_ctx* c, float* d_xyz, size_t n_vertices, i
     if (r) return r;
     if (steps <= 0 || n_vertices == 0) return 0;
     if (n_vertices > 0xffffff00ull) return fail(c, DCSG_ERR_INVALID, "too many vertices for one launch");
-    if (c->variant == 4 && !getenv("DCSG_PROJECT_WAVE_LISTS")) return project_cells(c, d_xyz, (unsigned)n_vertices, steps, (hipStream_t)stream);
+    if (c->variant == 4) return project_cells(c, d_xyz, (unsigned)n_vertices, steps, (hipStream_t)stream);
     const void* blob = c->d_blob.p;
     int nv = c->scene.blob_vec4();
     unsigned n = (unsigned)n_vertices;

@@ -961,14 +961,6 @@ __device__ __forceinline__ void dcsg_cache_step_bounds(const SceneLds& s, const 
     *dcsg_step_cache_at(c, 2 * t) = lb;
     *dcsg_step_cache_at(c, 2 * t + 1) = ub;
 }
-// Builds the wave's active-step list for the tile that contains the valid lanes' points (x,y,z); `pad` is
-// added to every half extent (the stencil's epsilon).  Returns the number of steps kept (wave-uniform).
-// `grow` (a fraction of the tile's largest half extent) widens the tile so that the list stays valid while the points move:
-// `reach`, when given, receives the tile's centre and the half extents within which a POINT may lie (its stencil then stays
-// inside the tile the bounds were taken over).
-struct DcsgTileReach {
-    float cx, cy, cz, ax, ay, az;
-};
 // The list for an explicit tile: centre (cx, cy, cz), half extents (hx, hy, hz) INCLUDING the stencil's pad.
 __device__ __forceinline__ int dcsg_build_active_list_box(const SceneLds& s, float cx, float cy, float cz, float hx, float hy, float hz,
                                                           unsigned short* list)
@@ -1041,19 +1033,17 @@ __device__ __forceinline__ int dcsg_build_active_list_box(const SceneLds& s, flo
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return n_active;
 }
+// The wave's list for the tile that contains the valid lanes' points (x, y, z); `pad` is added to every half extent (the
+// stencil's epsilon).  Returns the number of steps kept (wave-uniform).
 __device__ __forceinline__ int dcsg_build_active_list(const SceneLds& s, bool valid, float x, float y, float z, float pad,
-                                                      unsigned short* list, float grow, DcsgTileReach& reach)
+                                                      unsigned short* list)
 {
     const float inf = __builtin_inff();
     float x0 = wave_min_f(valid ? x : inf), x1 = wave_max_f(valid ? x : -inf);
     float y0 = wave_min_f(valid ? y : inf), y1 = wave_max_f(valid ? y : -inf);
     float z0 = wave_min_f(valid ? z : inf), z1 = wave_max_f(valid ? z : -inf);
-    float cx = 0.5f * (x0 + x1), cy = 0.5f * (y0 + y1), cz = 0.5f * (z0 + z1);
-    float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0), hz = 0.5f * (z1 - z0);
-    const float extra = grow * (fmaxf(hx, fmaxf(hy, hz)) + pad);
-    hx += extra, hy += extra, hz += extra;
-    reach = {cx, cy, cz, hx, hy, hz};  // before the stencil's pad: where the points themselves may be
-    return dcsg_build_active_list_box(s, cx, cy, cz, hx + pad, hy + pad, hz + pad, list);
+    return dcsg_build_active_list_box(s, 0.5f * (x0 + x1), 0.5f * (y0 + y1), 0.5f * (z0 + z1), 0.5f * (x1 - x0) + pad, 0.5f * (y1 - y0) + pad,
+                                      0.5f * (z1 - z0) + pad, list);
 }
 #define DCSG_HAVE_CULL 1
 #endif
@@ -2556,8 +2546,7 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
         float x = half_neg + cd * (float)ix;
         float y = half_neg + cd * (float)iy;
         float z = half_neg + cd * (float)iz;
-        DcsgTileReach unused;
-        int n_list = dcsg_build_active_list(s, true, x, y, z, 0.0f, list, 0.0f, unused);
+        int n_list = dcsg_build_active_list(s, true, x, y, z, 0.0f, list);
         float v, u0, u1, u2;
         dcsg_stencil<4>(s, x, y, z, true, false, v, u0, u1, u2, list, n_list);
         if ((double)__builtin_fabsf(v) < bb_eps) atomicAdd(&zh[iz + 128], 1u);
@@ -2661,100 +2650,11 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
     }
 }
 
-// Projection: consecutive vertices of the triangle buffer come from the same or neighbouring octree leaves,
-// so a wave's 64 vertices form a small cluster.  (At least 4 waves per SIMD, i.e. at most 128 VGPRs: with its two descent
-// loops the kernel was allocated 130 and lost a quarter of its waves.)
-#ifndef DCSG_PROJECT_C4_WAVES
-#define DCSG_PROJECT_C4_WAVES 4
-#endif
-extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, DCSG_PROJECT_C4_WAVES)
-dcsg_project_c4(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ verts, unsigned int n_verts, int steps)
-{
-    SceneLds s = dcsg_stage_scene(blob, n_vec4);
-    unsigned short* list = dcsg_wave_list(s, n_vec4);
-    const unsigned int tiles = (n_verts + DCSG_BLOCK - 1) / DCSG_BLOCK;
-    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        unsigned int i = tile * DCSG_BLOCK + threadIdx.x;
-        bool valid = i < n_verts;
-        unsigned int j = valid ? i : 0u;
-        DcsgDescent d = {verts[(size_t)j * 3 + 0], verts[(size_t)j * 3 + 1], verts[(size_t)j * 3 + 2], 0.0f, 0.0f, 0.0f, false, !valid};
-        // Plain unions (scene flag bit 1): the tile is the box of the vertices that are still moving, widened by a twentieth of
-        // its size, and the list is built again only when a moving vertex leaves that box or half of the vertices it was built
-        // for have retired (the tile of the rest is smaller, its list shorter) -- the steps shrink fast, so a few lists serve
-        // the whole descent (flat256 1024^3: 12.9 -> 11.6 ms).  Mixed joins at the root: a list per step, over the box of the
-        // vertices that are still moving (there the per-step list of the shrinking tile was the faster one).
-        // A LONG list means that the wave's vertices lie far apart (the order of the unique vertices is not coherent
-        // everywhere): such a wave used to run every object of the scene for all `steps` and set the kernel's duration on
-        // its own (VALU 5 % busy).  Its moving vertices are halved along the longest axis of their box, up to three times,
-        // each part with its own list; the parts are evaluated one after the other.  Retired lanes run along and are ignored.
-        // (Mixed scenes, where every list costs a walk of all groups: a longer threshold, and no more halving for a tile once a
-        // half's list came out barely shorter than the whole's -- smooth256 1024^3 19.9 -> 16.0 ms, 512^3 13.7 -> 12.6;
-        // grouped256 10.1 -> 10.3, 11.7 -> 9.4.)
-        const bool reuse = (s.flags & 2) != 0;
-        const int long_list = reuse ? (s.n_stack_steps / 4 > 48 ? s.n_stack_steps / 4 : 48) : (s.n_stack_steps / 2 > 96 ? s.n_stack_steps / 2 : 96);
-        const int lane = (int)(threadIdx.x & (DCSG_WAVE - 1u));
-        int n_list = 0, built_for = 0;  // built_for: the number of moving vertices the list was built for; 0 = not for all of them
-        DcsgTileReach reach = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        bool halving_pays = true;  // until a half's list comes out barely shorter than the whole's (a densely populated tile)
-        int parent_list = 0;
-        for (int k = 0; k < steps; k++) {
-            const unsigned long long moving = __builtin_amdgcn_ballot_w64(!d.done);
-            if (moving == 0ull) break;
-            const float x = d.x, y = d.y, z = d.z;
-            float qx = x, qy = y, qz = z;  // the step's result F(p) per lane
-            unsigned long long pending = moving;
-            while (pending != 0ull) {  // wave-uniform: one round per part (one round for almost every wave)
-                bool in_part = ((pending >> lane) & 1ull) != 0ull;
-                bool build = true;
-                float grow = 0.0f;
-                if (pending == moving && reuse) {
-                    const bool outside = in_part && !(__builtin_fabsf(x - reach.cx) <= reach.ax && __builtin_fabsf(y - reach.cy) <= reach.ay &&
-                                                      __builtin_fabsf(z - reach.cz) <= reach.az);
-                    build = built_for == 0 || 2 * __popcll(moving) <= built_for || __builtin_amdgcn_ballot_w64(outside) != 0ull;
-                    grow = 0.05f;
-                }
-                for (int halvings = 0;; halvings++) {
-                    if (build) {
-                        n_list = dcsg_build_active_list(s, in_part, x, y, z, (float)K2_NORMAL_EPSILON * 1.01f, list, grow, reach);
-                        built_for = (pending == moving && halvings == 0) ? __popcll(moving) : 0;
-                    }
-                    // mixed scenes (a list costs a walk of every group): a half whose list is barely shorter ends the halving for this tile
-                    if (!reuse && halvings > 0 && 4 * n_list > 3 * parent_list) halving_pays = false;
-                    if (n_list <= long_list || halvings == 3 || !halving_pays) break;
-                    parent_list = n_list;
-                    // the half (along the longest axis of the part's box) that holds the part's first vertex
-                    const float c = reach.ax >= reach.ay && reach.ax >= reach.az ? x - reach.cx : (reach.ay >= reach.az ? y - reach.cy : z - reach.cz);
-                    const unsigned long long part = __builtin_amdgcn_ballot_w64(in_part);
-                    const unsigned long long low = __builtin_amdgcn_ballot_w64(in_part && c <= 0.0f);
-                    const unsigned long long keep = ((low >> __builtin_ctzll(part)) & 1ull) ? low : part & ~low;
-                    if (keep == part) break;  // all on one side (coincident vertices): no further
-                    in_part = ((keep >> lane) & 1ull) != 0ull;
-                    build = true;
-                    grow = 0.0f;
-                }
-                float psd, pnx, pny, pnz;
-                dcsg_stencil<4>(s, x, y, z, true, true, psd, pnx, pny, pnz, list, n_list);
-                if (in_part) {
-                    const float m = -psd;
-                    qx = x + m * pnx, qy = y + m * pny, qz = z + m * pnz;
-                }
-                pending &= ~__builtin_amdgcn_ballot_w64(in_part);
-            }
-            dcsg_descent_advance(d, qx, qy, qz, k, steps);
-        }
-        if (valid) {
-            verts[(size_t)i * 3 + 0] = d.x;
-            verts[(size_t)i * 3 + 1] = d.y;
-            verts[(size_t)i * 3 + 2] = d.z;
-        }
-    }
-}
-
 #ifdef DCSG_PART_EXPORT
 // ---------------------------------------------------------------------------
 // Cell lists: the projection of many-object scenes (and whatever else evaluates them at scattered points).
 //
-// dcsg_project_c4 builds its list per WAVE, over the box of the wave's 64 vertices: a wave whose vertices lie far apart
+// Rounds 1-3 built the projection's list per WAVE, over the box of the wave's 64 vertices: a wave whose vertices lie far apart
 // (the order of the distinct vertices follows the octree, which jumps; vertices hop to other objects while they descend)
 // gets the whole scene for all its steps and sets the kernel's duration on its own (round 3: 24 576 waves of 0.17 M
 // cycles each in a kernel of 25 M cycles, VALU 5 % busy).  Here the tile belongs to SPACE, not to a wave: a cube of g^3

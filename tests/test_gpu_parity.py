@@ -565,7 +565,7 @@ def test_cell_list_projection(ev, oracle, name, monkeypatch):
     over the scene, each LANE interpreting the list of the cell its vertex is in, idle lanes refilled from a queue).
     Against the oracle, bit for bit, on vertices in no order at all: uniform in the scene, far outside the cube (the
     pseudo-cell of the whole program), on cell faces, with -0.0 coordinates, NaN and infinity; few and many steps, several
-    grid resolutions and refill thresholds; and against the per-wave lists (DCSG_PROJECT_WAVE_LISTS) it replaces."""
+    grid resolutions and refill thresholds."""
     import torch
     monkeypatch.setenv("DCSG_CULL", "8")      # mixed_groups (21 objects) takes the culling kernels too ...
     monkeypatch.setenv("DCSG_SPECIALISE", "0")  # ... when it is not given per-scene code
@@ -590,9 +590,8 @@ def test_cell_list_projection(ev, oracle, name, monkeypatch):
     with np.errstate(all="ignore"):
         for steps, n in ((1, 20_000), (9, 20_000), (50, 6_000)):
             want = osc.gradient_descent(pts[:n - n % 3].reshape(-1, 3, 3), steps).reshape(-1, 3)
-            for env in ({}, {"DCSG_CELLS": "16"}, {"DCSG_CELLS": "97", "DCSG_PROJECT_REFILL": "1"}, {"DCSG_PROJECT_REFILL": "64"},
-                        {"DCSG_PROJECT_WAVE_LISTS": "1"}):
-                if steps == 50 and env and "DCSG_PROJECT_WAVE_LISTS" not in env:
+            for env in ({}, {"DCSG_CELLS": "16"}, {"DCSG_CELLS": "97", "DCSG_PROJECT_REFILL": "1"}, {"DCSG_PROJECT_REFILL": "64"}):
+                if steps == 50 and env:
                     continue
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
