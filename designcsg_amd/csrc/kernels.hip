@@ -2795,17 +2795,21 @@ dcsg_cells_build(const uint4* __restrict__ blob, int n_vec4, DcsgCellGrid G, uin
 // one group: csrc/scene.cpp builds items only then).  The stencil as the reference forms it, v +- (eps, 0, 0): the
 // other coordinates of a "+" point are c + 0.0f, of a "-" point c - 0.0f = c -- kept apart here, so a -0.0 coordinate
 // needs no special path.
+template <int N>  // N = 7: the stencil of get_normal around (x, y, z); N = 1: the point itself
 __device__ __forceinline__ void dcsg_interp_lanes(const SceneLds& s, const unsigned int* __restrict__ entries, unsigned int first,
-                                                  unsigned int count, float x, float y, float z, float (&out)[7])
+                                                  unsigned int count, float x, float y, float z, float (&out)[N])
 {
     const float e = (float)K2_NORMAL_EPSILON, zero = 0.0f;
     const float xz = x + zero, yz = y + zero, zz = z + zero;
-    const float px[7] = {x, x + e, x - e, xz, x, xz, x};
-    const float py[7] = {y, yz, y, y + e, y - e, yz, y};
-    const float pz[7] = {z, zz, z, zz, z, z + e, z - e};
-    float top[7], below[7];
+    const float px7[7] = {x, x + e, x - e, xz, x, xz, x};
+    const float py7[7] = {y, yz, y, y + e, y - e, yz, y};
+    const float pz7[7] = {z, zz, z, zz, z, z + e, z - e};
+    float px[N], py[N], pz[N];
 #pragma unroll
-    for (int k = 0; k < 7; k++) top[k] = below[k] = 0.0f, out[k] = (float)K2_MAX_DISTANCE;
+    for (int k = 0; k < N; k++) px[k] = px7[k], py[k] = py7[k], pz[k] = pz7[k];
+    float top[N], below[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) top[k] = below[k] = 0.0f, out[k] = (float)K2_MAX_DISTANCE;
     float bk = 0.0f, inv_bk = 0.0f;
     const unsigned int longest = (unsigned int)wave_max((int)count);
     unsigned int next = count ? entries[first] : 0u;
@@ -2816,56 +2820,56 @@ __device__ __forceinline__ void dcsg_interp_lanes(const SceneLds& s, const unsig
         const int op = (int)((ent >> 24) & 0x3fu) + 32;
         const bool leaf = op <= SOP_ACC_NEGMAX || (op >= SOP_ACC_SMIN && op <= SOP_ACC_NEGSMAX);
         if (leaf) {
-            float r[7];
+            float r[N];
             const int shape = (int)((ent >> 16) & 0xffu);
             if (shape == 0 && (s.flags & 1)) {
 #pragma unroll
-                for (int k = 0; k < 7; k++) r[k] = (float)K2_MAX_DISTANCE;
+                for (int k = 0; k < N; k++) r[k] = (float)K2_MAX_DISTANCE;
             } else {
                 const unsigned int obj = ent & 0xffffu;
                 const float4 q0 = s.obj[4u * obj + 0u], q1 = s.obj[4u * obj + 1u], q2 = s.obj[4u * obj + 2u], q3 = s.obj[4u * obj + 3u];
-                float A[7], B[7], C[7];
+                float A[N], B[N], C[N];
 #pragma unroll
-                for (int k = 0; k < 7; k++) {
+                for (int k = 0; k < N; k++) {
                     float dx = px[k] - q0.x, dy = py[k] - q0.y, dz = pz[k] - q0.z;  // k2.cl:105-111
                     A[k] = dx * q1.x + dy * q1.y + dz * q1.z;
                     B[k] = dx * q2.x + dy * q2.y + dz * q2.z;
                     C[k] = dx * q3.x + dy * q3.y + dz * q3.z;
                 }
-                dcsg_bank_n<7>(A, B, C, shape, r);
+                dcsg_bank_n<N>(A, B, C, shape, r);
             }
             if (op == SOP_PUSH) {
                 if (ent >> 30 & 1u) {
 #pragma unroll
-                    for (int k = 0; k < 7; k++) below[k] = top[k];
+                    for (int k = 0; k < N; k++) below[k] = top[k];
                 }
 #pragma unroll
-                for (int k = 0; k < 7; k++) top[k] = r[k];
+                for (int k = 0; k < N; k++) top[k] = r[k];
             } else if (op == SOP_ACC_MIN) {
 #pragma unroll
-                for (int k = 0; k < 7; k++) top[k] = top[k] < r[k] ? top[k] : r[k];
+                for (int k = 0; k < N; k++) top[k] = top[k] < r[k] ? top[k] : r[k];
             } else if (op == SOP_ACC_MAX) {
 #pragma unroll
-                for (int k = 0; k < 7; k++) top[k] = top[k] > r[k] ? top[k] : r[k];
+                for (int k = 0; k < N; k++) top[k] = top[k] > r[k] ? top[k] : r[k];
             } else if (op == SOP_ACC_NEGMAX) {
 #pragma unroll
-                for (int k = 0; k < 7; k++) {
+                for (int k = 0; k < N; k++) {
                     float nb = -r[k];
                     top[k] = top[k] > nb ? top[k] : nb;
                 }
             } else if (op == SOP_ACC_SMIN) {
 #pragma unroll
-                for (int k = 0; k < 7; k++) top[k] = dcsg_smin(top[k], r[k], bk, inv_bk);
+                for (int k = 0; k < N; k++) top[k] = dcsg_smin(top[k], r[k], bk, inv_bk);
             } else if (op == SOP_ACC_SMAX) {
 #pragma unroll
-                for (int k = 0; k < 7; k++) top[k] = dcsg_smax(top[k], r[k], bk, inv_bk);
+                for (int k = 0; k < N; k++) top[k] = dcsg_smax(top[k], r[k], bk, inv_bk);
             } else {
 #pragma unroll
-                for (int k = 0; k < 7; k++) top[k] = dcsg_smax(top[k], -r[k], bk, inv_bk);
+                for (int k = 0; k < N; k++) top[k] = dcsg_smax(top[k], -r[k], bk, inv_bk);
             }
         } else if (op <= SOP_POP_NEGMAX || (op >= SOP_POP_SMIN && op <= SOP_POP_NEGSMAX)) {
 #pragma unroll
-            for (int k = 0; k < 7; k++) {
+            for (int k = 0; k < N; k++) {
                 float a = below[k], b = top[k];
                 if (op == SOP_POP_MIN) top[k] = a < b ? a : b;
                 else if (op == SOP_POP_MAX) top[k] = a > b ? a : b;
@@ -2878,7 +2882,7 @@ __device__ __forceinline__ void dcsg_interp_lanes(const SceneLds& s, const unsig
             }
         } else if (op == SOP_EXPORT_TOP) {
 #pragma unroll
-            for (int k = 0; k < 7; k++) out[k] = top[k];
+            for (int k = 0; k < N; k++) out[k] = top[k];
         } else if (op == SOP_SET_K) {
             const int4 st = s.stack_steps[ent & 0xffffu];
             bk = __int_as_float(st.y);
@@ -2950,7 +2954,7 @@ dcsg_project_cells(const uint4* __restrict__ blob, int n_vec4, float* __restrict
             cl = cells[n_cells + 1u + ((iz / DCSG_CELL_COARSE) * gc + iy / DCSG_CELL_COARSE) * gc + ix / DCSG_CELL_COARSE];
         }
         float o[7];
-        dcsg_interp_lanes(s, entries, cl.x, cl.y, x, y, z, o);
+        dcsg_interp_lanes<7>(s, entries, cl.x, cl.y, x, y, z, o);
         if (!d.done) {
             float nx, ny, nz;
             dcsg_finish_normal(o[1] - o[2], o[3] - o[4], o[5] - o[6], nx, ny, nz);
@@ -2965,6 +2969,49 @@ dcsg_project_cells(const uint4* __restrict__ blob, int n_vec4, float* __restrict
             }
         }
     }
+}
+
+// Stage A of a culling scene over the cell lists: the 256^3 probes in bricks of 4 x 4 x 4 per wave as dcsg_bbox_c4 takes them,
+// each lane reading the list of the cell ITS probe is in -- the fine cell where an earlier projection built it, the coarse
+// cell around it otherwise (all of those exist), the whole program outside the cube -- instead of every wave bounding all
+// the scene's items for its 64 probes.  Same values, same reduction.
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_bbox_cells(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, double bb_eps, int* __restrict__ result,
+                DcsgCellGrid G, const uint2* __restrict__ cells, const unsigned int* __restrict__ entries)
+{
+    SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    DCSG_BBOX_ZHIST_DECL
+    const unsigned int total = 256u * 256u * 256u;  // a multiple of the block size: every lane is valid
+    const unsigned int g = (unsigned int)G.g, n_cells = g * g * g, gc = g / DCSG_CELL_COARSE;
+    int mn[3] = {1 << 20, 1 << 20, 1 << 20};
+    int mx[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
+    unsigned int cnt = 0;
+    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < total; i += gridDim.x * DCSG_BLOCK) {
+        int iz = (int)((((i >> 6) & 63u) << 2) | (i & 3u)) - 128;
+        int iy = (int)((((i >> 12) & 63u) << 2) | ((i >> 2) & 3u)) - 128;
+        int ix = (int)(((i >> 18) << 2) | ((i >> 4) & 3u)) - 128;
+        float x = half_neg + cd * (float)ix;
+        float y = half_neg + cd * (float)iy;
+        float z = half_neg + cd * (float)iz;
+        unsigned int cx = 0u, cy = 0u, cz = 0u;
+        const unsigned int cell = dcsg_cell_of(G, x, y, z, cx, cy, cz);
+        uint2 cl = cells[cell];
+        if (cl.y == DCSG_CELL_NOT_BUILT) cl = cells[n_cells + 1u + ((cz / DCSG_CELL_COARSE) * gc + cy / DCSG_CELL_COARSE) * gc + cx / DCSG_CELL_COARSE];
+        float o[1];
+        dcsg_interp_lanes<1>(s, entries, cl.x, cl.y, x, y, z, o);
+        const float v = o[0];
+        if ((double)__builtin_fabsf(v) < bb_eps) atomicAdd(&zh[iz + 128], 1u);
+        if ((double)v < bb_eps) {
+            cnt++;
+            mn[0] = ix < mn[0] ? ix : mn[0];
+            mx[0] = ix > mx[0] ? ix : mx[0];
+            mn[1] = iy < mn[1] ? iy : mn[1];
+            mx[1] = iy > mx[1] ? iy : mx[1];
+            mn[2] = iz < mn[2] ? iz : mn[2];
+            mx[2] = iz > mx[2] ? iz : mx[2];
+        }
+    }
+    dcsg_bbox_commit(mn, mx, cnt, result, zh);
 }
 #endif  // DCSG_PART_EXPORT (cell lists)
 #endif
