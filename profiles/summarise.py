@@ -19,6 +19,27 @@ def main(tag):
     dst = os.path.join(ROOT, "profiles")
     shutil.copyfile(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
     shutil.copyfile(os.path.join(src, "stats_bench.json"), os.path.join(dst, tag + "_bench.json"))
+    # rocprofv3's --stats averages mix the launches from idle clocks (scene loading leaves the GPU idle; bench.py's
+    # from_idle figure) with the settled ones: per kernel also the median, the minimum and the mean of the LAST `steps`
+    # launches -- the timed region of the bench line, which is what `ms_per_step` and `roofline.kernel_ms` are taken over
+    trace = os.path.join(src, "stats", "stats_kernel_trace.csv")
+    if os.path.exists(trace):
+        try:
+            steps = int(json.load(open(os.path.join(src, "stats_bench.json"))).get("steps", 20))
+        except (OSError, ValueError):
+            steps = 20
+        dur = collections.defaultdict(list)
+        rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
+        for r in rows:
+            dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        med = {}
+        for k, v in dur.items():
+            if not k.startswith("dcsg_"):
+                continue
+            sv = sorted(v)
+            med[k] = {"launches": len(v), "mean_ms": round(sum(v) / len(v), 5), "median_ms": round(sv[len(sv) // 2], 5), "min_ms": round(sv[0], 5),
+                      "max_ms": round(sv[-1], 5), "timed_region_mean_ms": round(sum(v[-steps:]) / len(v[-steps:]), 5), "timed_region_launches": len(v[-steps:])}
+        json.dump(med, open(os.path.join(dst, tag + "_kernel_medians.json"), "w"), indent=1, sort_keys=True)
     out = {}
     for sub, name in (("pmc_sq", "sq"), ("pmc_sq2", "sq2"), ("pmc_write", "wr"), ("pmc_fetch", "rd")):
         f = os.path.join(src, sub, name + "_counter_collection.csv")
