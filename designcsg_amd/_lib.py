@@ -98,6 +98,7 @@ PROTOTYPES = {
                                        C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "dcsg_expand_lookup_table": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]),
     "dcsg_angle_q_star": (C.c_float, [C.c_float]),
+    "dcsg_debug_slab_cuts": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dcsg_debug_cells": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "dcsg_debug_sqrt_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "dcsg_debug_normal_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),

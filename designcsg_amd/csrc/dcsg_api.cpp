@@ -1013,6 +1013,7 @@ int dcsg_eval_lattice(dcsg_ctx* c, const float center[3], const float diameters[
 
 // Stage A, DesignCSG.cpp:668-712
 namespace {
+bool slab_cut_planes(const dcsg_ctx* c, const dcsg_export_config& cfg, float center_z, float diameter, int rank, int world, int& z_lo, int& z_hi);
 int cells_for_stage_a(dcsg_ctx* c, hipStream_t s, float probe_half);  // grid + the cells every scene has (coarse cells, the whole program)
 }
 
@@ -1458,6 +1459,33 @@ int project_cells(dcsg_ctx* c, float* d_xyz, unsigned n, int steps, hipStream_t 
 }  // namespace
 
 extern "C" {
+
+// Diagnostic, no device needed: the cut planes dcsg_export_slab derives from a stage-A histogram (256 counts of near-surface
+// probes per probe plane z = half_neg + cd (k - 128)) for a box of `diameter` centred at center_z: cuts[0 .. world] in
+// lattice planes (cuts[r] .. cuts[r + 1] is rank r's slab).  Returns 0, or DCSG_ERR_INVALID when the equal slabs would be
+// kept (sweep level coarser than the slabs, empty histogram: cuts then hold the equal slabs).
+int dcsg_debug_slab_cuts(const uint32_t hist[256], float cd, float half_neg, float center_z, float diameter, int min_level, int grid_level,
+                         int world, int* cuts)
+{
+    if (!hist || !cuts || world < 1 || grid_level < 1 || grid_level > 12 || ((1 << grid_level) % world) != 0) return DCSG_ERR_INVALID;
+    dcsg_ctx tmp;
+    memcpy(tmp.probe_z_hist, hist, sizeof(tmp.probe_z_hist));
+    tmp.probe_cd = cd;
+    tmp.probe_half_neg = half_neg;
+    dcsg_export_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.min_level = min_level;
+    cfg.grid_level = grid_level;
+    const int res = 1 << grid_level;
+    bool balanced = false;
+    for (int r = 0; r < world; r++) {
+        int lo = r * (res / world), hi = (r + 1) * (res / world);
+        balanced = slab_cut_planes(&tmp, cfg, center_z, diameter, r, world, lo, hi);
+        cuts[r] = lo;
+        cuts[r + 1] = hi;
+    }
+    return balanced ? 0 : DCSG_ERR_INVALID;
+}
 
 int dcsg_debug_cells(const dcsg_ctx* c, int* grid, uint64_t* cells_built, uint64_t* entries, double* build_ms)
 {
@@ -2248,14 +2276,15 @@ namespace {
 // the same 256 integers (same kernel, same scene: no communication).  The N - 1 cut planes put an N-th of that count into
 // each slab, snapped to node boundaries of the sweep level (a node of that level must not straddle slabs) with at least
 // one node per slab; with an empty histogram the equal slabs stay.
-void slab_cut_planes(const dcsg_ctx* c, const dcsg_export_config& cfg, float center_z, float diameter, int rank, int world, int& z_lo, int& z_hi)
+// Returns false (z_lo / z_hi untouched: the equal slabs) when there is nothing to balance on.
+bool slab_cut_planes(const dcsg_ctx* c, const dcsg_export_config& cfg, float center_z, float diameter, int rank, int world, int& z_lo, int& z_hi)
 {
     const int res = 1 << cfg.grid_level;
     const int sweep_level = cfg.min_level > 2 ? cfg.min_level : 2;
     const int level = sweep_level <= cfg.grid_level ? sweep_level : cfg.grid_level;
     const int node = res >> level;       // lattice planes per node of the sweep level
     const int n_nodes = 1 << level;      // candidate cut planes: node * k
-    if (n_nodes < world || node < 1) return;
+    if (n_nodes < world || node < 1) return false;
     // work per node layer: the probe planes' counts spread over the lattice planes they cover
     std::vector<double> layer((size_t)n_nodes, 0.0);
     const double z0 = (double)center_z - 0.5 * (double)diameter, step = (double)diameter / res;
@@ -2269,7 +2298,7 @@ void slab_cut_planes(const dcsg_ctx* c, const dcsg_export_config& cfg, float cen
         layer[(size_t)l] += c->probe_z_hist[k];
         total += c->probe_z_hist[k];
     }
-    if (!(total > 0)) return;
+    if (!(total > 0)) return false;
     // every layer also carries a small constant (an empty slab still costs its launches): 2 % of the mean
     const double floor_w = 0.02 * total / n_nodes;
     for (auto& w : layer) w += floor_w;
@@ -2291,6 +2320,7 @@ void slab_cut_planes(const dcsg_ctx* c, const dcsg_export_config& cfg, float cen
     for (; k < world; k++) cut[(size_t)k] = std::max(cut[(size_t)k - 1] + 1, n_nodes - (world - k));
     z_lo = cut[(size_t)rank] * node;
     z_hi = cut[(size_t)rank + 1] * node;
+    return true;
 }
 
 // Stages A .. projection of the export for Z slab `rank` of `world` (world = 1: the whole box).  Rank r owns the octree

@@ -265,6 +265,12 @@ float dcsg_angle_q_star(float complex_surface_threshold);
 /* Diagnostic: the flags word of the loaded scene's device tables (csrc/scene.cpp build_blob): bit 0 = the null brush is a
  * constant, bit 1 = the root accumulator is a plain union (the tile culling's order-free rule applies). */
 int dcsg_debug_scene_flags(const dcsg_ctx* ctx, int* flags);
+/* Diagnostic, no device needed: the work-balanced cut planes of dcsg_export_slab for a given stage-A histogram (256 counts of
+ * near-surface probes per probe plane z = half_neg + cd (k - 128)), a box of `diameter` centred at center_z in z, and the
+ * export levels: cuts[0 .. world], rank r owning lattice planes [cuts[r], cuts[r + 1]).  Returns DCSG_ERR_INVALID (cuts = the
+ * equal slabs) when the equal slabs are kept. */
+int dcsg_debug_slab_cuts(const uint32_t hist[256], float cd, float half_neg, float center_z, float diameter, int min_level, int grid_level,
+                         int world, int* cuts);
 /* Diagnostic: the cell lists of the loaded many-object scene (vertex projection, DESIGN.md "Cell lists"): cells per axis
  * (0 = no grid yet), cells built (fine, coarse and the pseudo-cell of the whole program) and list entries handed out so far,
  * host milliseconds spent building cells since the scene was loaded. */

@@ -556,3 +556,47 @@ def test_brush_jit_without_a_gpu(built_lib, tmp_path, monkeypatch):
     bad = src.replace(b"hilbert_sdf(v)", b"no_such_function(v)")
     assert built_lib.dcsg_jit_prebuild(bad, log, len(log), C.byref(cached)) == -4
     assert b"no_such_function" in log.value
+
+
+def test_balanced_slab_cuts(built_lib):
+    """dcsg_export_slab's cut planes from a stage-A histogram (no device: dcsg_debug_slab_cuts).  Work concentrated in the
+    middle of the box (Design2-like), off-centre, in a single plane, and absent: the cuts tile 0 .. res, sit on node
+    boundaries of the sweep level, give every slab at least one node layer, and balance the histogram."""
+    import ctypes as C
+    L = built_lib
+    cd, half_neg, center_z, diameter = np.float32(10.0 / 256), np.float32(-10.0 / 512), 0.0, 9.3359375
+    z = half_neg + cd * (np.arange(256) - 128)
+
+    def cuts_for(hist, min_level, grid_level, world):
+        h = np.ascontiguousarray(hist, dtype=np.uint32)
+        out = np.zeros(world + 1, dtype=np.int32)
+        rc = L.dcsg_debug_slab_cuts(h.ctypes.data_as(C.c_void_p), C.c_float(cd), C.c_float(half_neg), C.c_float(center_z), C.c_float(diameter),
+                                    min_level, grid_level, world, out.ctypes.data_as(C.c_void_p))
+        return rc, out
+
+    def work(hist, cuts, res):
+        lat = (z - (center_z - diameter / 2)) / (diameter / res)       # lattice plane of every probe plane
+        return [float(hist[(lat >= a) & (lat < b)].sum()) for a, b in zip(cuts[:-1], cuts[1:])]
+
+    middle = (2000 * np.exp(-(z / 1.2) ** 2)).astype(np.uint32)          # a blob in the middle of the box
+    for world in (2, 4, 8):
+        rc, cuts = cuts_for(middle, 7, 10, world)
+        assert rc == 0 and cuts[0] == 0 and cuts[-1] == 1024 and np.all(np.diff(cuts) >= 8) and np.all(cuts % 8 == 0), cuts
+        w = work(middle, cuts, 1024)
+        assert max(w) < 1.35 * sum(w) / world, (world, cuts, w)
+        equal = work(middle, np.arange(world + 1) * (1024 // world), 1024)
+        if world > 2:
+            assert max(equal) > 1.5 * sum(equal) / world          # what equal slabs would have done
+    off = np.roll(middle, 60)                                            # the same blob off-centre
+    rc, cuts = cuts_for(off, 7, 10, 8)
+    assert rc == 0 and np.all(np.diff(cuts) >= 8) and max(work(off, cuts, 1024)) < 1.4 * off.sum() / 8
+    spike = np.zeros(256, dtype=np.uint32)
+    spike[100] = 5000                                                    # everything in one probe plane: still a valid tiling
+    rc, cuts = cuts_for(spike, 7, 10, 8)
+    assert rc == 0 and cuts[0] == 0 and cuts[-1] == 1024 and np.all(np.diff(cuts) >= 8)
+    rc, cuts = cuts_for(np.zeros(256, dtype=np.uint32), 7, 10, 8)        # nothing near a surface: the equal slabs stay
+    assert rc != 0 and cuts.tolist() == [128 * k for k in range(9)]
+    rc, cuts = cuts_for(middle, 2, 6, 8)                                 # sweep level 2 has 4 node layers < 8 slabs: equal slabs
+    assert rc != 0 and cuts.tolist() == [8 * k for k in range(9)]
+    rc, cuts = cuts_for(middle, 3, 6, 8)                                 # exactly one node layer per slab
+    assert cuts.tolist() == [8 * k for k in range(9)]
