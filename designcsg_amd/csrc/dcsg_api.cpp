@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -125,8 +127,16 @@ struct dcsg_ctx {
     // pinned host words for the small read-backs (counts, totals, the bounding-box words): a copy into pageable memory goes
     // through the runtime's staging path and costs tens of microseconds more, a dozen times per export
     unsigned char* h_words = nullptr;  // 8 KiB
-    void* h_pinned = nullptr;  // host staging for triangle downloads
+    void* h_pinned = nullptr;  // host staging of the WHOLE triangle buffer (opt-in writers only, which need all of it at once)
     size_t h_pinned_cap = 0;
+    // The reference writers stream: a ring of pinned slots that downloads fill and the two writers drain, allocated once
+    // per context (pinning memory costs 5-25 ms per 100 MB on the pool's boxes, and the whole-buffer staging of rounds 1-3
+    // paid it on every first export of a larger mesh: 6.7 ms of a 25.9 ms Design2 1024^3 export)
+    static constexpr int kRingSlots = 4;
+    static constexpr size_t kRingSlotBytes = (size_t)16 << 20;
+    unsigned char* h_ring = nullptr;
+    size_t ring_slot_bytes = 0;
+    hipEvent_t ring_ev[kRingSlots] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t sweep_ev[8][2] = {};  // timing events of the dense sweeps, used in turn (sweep_device)
     int sweep_ev_next = 0;
@@ -682,6 +692,9 @@ void dcsg_destroy(dcsg_ctx* c)
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_words) hipHostFree(c->h_words);
+    if (c->h_ring) hipHostFree(c->h_ring);
+    for (auto& e : c->ring_ev)
+        if (e) hipEventDestroy(e);
     join_rest_thread(c);
     if (c->scene_mod) hipModuleUnload(c->scene_mod);
     if (c->scene_mod_rest) hipModuleUnload(c->scene_mod_rest);
@@ -2473,6 +2486,119 @@ int stage_triangles_on_host(dcsg_ctx* c, float** host)
     return dcsg_download_triangles(c, *host, c->n_tris);
 }
 
+
+// The context's triangles -> stl_path / ply_path (reference layouts; either may be NULL) as triangles [first, first + n_tris)
+// of files of `total`, streamed through the pinned ring: the copy engine fills a slot while the two writers (one thread per
+// file, each formatting with its own helpers: write_range) drain earlier ones.  wflags: DCSG_WRITE_BEGIN is applied with the
+// first piece, DCSG_WRITE_END with the last.  Tb / K: chunk boundaries of a pipelined projection -- a piece is downloaded
+// once the chunk holding its last triangle is projected (chunk_ready[k], recorded on the context's stream); K = 0: the
+// triangles are final (the caller has synchronised).  t_last: when the last piece was on the host.
+int stream_triangles_to_files(dcsg_ctx* c, const char* stl_path, const char* ply_path, uint64_t first, uint64_t total, unsigned wflags,
+                              int K, const uint64_t* Tb, double& dt_stl, double& dt_ply, double& t_last)
+{
+    const uint64_t T = c->n_tris;
+    const int n_writers = (stl_path ? 1 : 0) + (ply_path ? 1 : 0);
+    dt_stl = dt_ply = t_last = 0;
+    if (!n_writers) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    {   // the ring: four slots of a quarter of the mesh each, between 1 and 16 MiB (a small mesh does not pay for pinning
+        // 64 MiB); grown when a larger mesh comes
+        size_t want = (((size_t)T * 9 * sizeof(float) / dcsg_ctx::kRingSlots) + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+        want = want > dcsg_ctx::kRingSlotBytes ? dcsg_ctx::kRingSlotBytes : want;
+        if (!c->h_ring || want > c->ring_slot_bytes) {
+            HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+            if (c->h_ring) HIPCHK(c, hipHostFree(c->h_ring));
+            c->h_ring = nullptr;
+            HIPCHK(c, hipHostMalloc((void**)&c->h_ring, dcsg_ctx::kRingSlots * want, hipHostMallocDefault));
+            c->ring_slot_bytes = want;
+        }
+        for (auto& e : c->ring_ev)
+            if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int S = dcsg_ctx::kRingSlots;
+    const size_t slot_bytes = c->ring_slot_bytes;
+    const uint64_t P = (slot_bytes / (9 * sizeof(float))) & ~(uint64_t)255;  // triangles per piece
+    // pieces never straddle the chunks of a pipelined projection (a piece is downloaded when ITS chunk is ready)
+    struct Piece {
+        uint64_t t, n;
+        int chunk;
+    };
+    std::vector<Piece> pieces;
+    for (int k = 0; k < (K > 0 ? K : 1); k++) {
+        const uint64_t lo = K > 0 ? Tb[k] : 0, hi = K > 0 ? Tb[k + 1] : T;
+        for (uint64_t t = lo; t < hi; t += P) pieces.push_back({t, std::min<uint64_t>(P, hi - t), k});
+    }
+    if (pieces.empty()) pieces.push_back({0, 0, 0});  // an empty mesh still carries BEGIN / END
+    const uint64_t n_pieces = pieces.size();
+    const float* d_tris = (const float*)c->d_tris.p;
+    std::mutex m;
+    std::condition_variable cv;
+    uint64_t enqueued = 0;
+    std::vector<int> finished((size_t)n_pieces, 0);
+    bool failed = false;
+    int rc_w[2] = {0, 0};
+    double busy[2] = {0, 0};
+    auto writer = [&](int idx, const char* path, bool ply) {
+        const double a = now_s();
+        hipSetDevice(c->device);
+        for (uint64_t j = 0; j < n_pieces; j++) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return enqueued > j || failed; });
+                if (failed) break;
+            }
+            const uint64_t t_j = pieces[(size_t)j].t, n_j = pieces[(size_t)j].n;
+            if (n_j && hipEventSynchronize(c->ring_ev[j % S]) != hipSuccess) rc_w[idx] = DCSG_ERR_HIP;
+            if (j + 1 == n_pieces && !ply) t_last = now_s();
+            const unsigned fl = (j == 0 ? (wflags & DCSG_WRITE_BEGIN) : 0u) | (j + 1 == n_pieces ? (wflags & DCSG_WRITE_END) : 0u);
+            if (!rc_w[idx]) rc_w[idx] = write_range(path, (const float*)(c->h_ring + (j % S) * slot_bytes), n_j, first + t_j, total, fl, ply);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                finished[(size_t)j]++;
+                if (rc_w[idx]) failed = true;
+            }
+            cv.notify_all();
+            if (rc_w[idx]) break;
+        }
+        busy[idx] = now_s() - a;
+    };
+    std::thread th_stl, th_ply;
+    if (stl_path) th_stl = std::thread([&] { writer(0, stl_path, false); });
+    if (ply_path) th_ply = std::thread([&] { writer(1, ply_path, true); });
+    // the director: slot j % S is free once both writers are done with piece j - S
+    hipError_t he = hipSuccess;
+    for (uint64_t j = 0; j < n_pieces && he == hipSuccess; j++) {
+        if (j >= (uint64_t)S) {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return finished[(size_t)(j - S)] == n_writers || failed; });
+            if (failed) break;
+        }
+        const uint64_t t_j = pieces[(size_t)j].t, n_j = pieces[(size_t)j].n;
+        if (n_j) {
+            if (K > 0) he = hipStreamWaitEvent(c->copy_stream, c->chunk_ready[pieces[(size_t)j].chunk], 0);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(c->h_ring + (j % S) * slot_bytes, d_tris + t_j * 9, (size_t)n_j * 9 * sizeof(float), hipMemcpyDeviceToHost,
+                                    c->copy_stream);
+            if (he == hipSuccess) he = hipEventRecord(c->ring_ev[j % S], c->copy_stream);
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (he == hipSuccess) enqueued = j + 1;
+            else failed = true;
+        }
+        cv.notify_all();
+    }
+    if (th_stl.joinable()) th_stl.join();
+    if (th_ply.joinable()) th_ply.join();
+    hipStreamSynchronize(c->copy_stream);
+    dt_stl = busy[0];
+    dt_ply = busy[1];
+    if (he != hipSuccess) return fail(c, DCSG_ERR_HIP, std::string("triangle download: ") + hipGetErrorString(he));
+    if (rc_w[0]) return fail(c, rc_w[0], "cannot write STL");
+    if (rc_w[1]) return fail(c, rc_w[1], "cannot write PLY");
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2513,15 +2639,6 @@ int project_download_write(dcsg_ctx* c, int steps, const char* stl_path, const c
         for (int k = 1; k < K; k++) Sb[k] = got[k - 1];
         Sb[K] = d.n_unique;
     }
-    size_t need = (size_t)T * 9 * sizeof(float) + 64;
-    if (need > c->h_pinned_cap) {
-        if (c->h_pinned) hipHostFree(c->h_pinned);
-        c->h_pinned = nullptr;
-        c->h_pinned_cap = 0;
-        HIPCHK(c, hipHostMalloc(&c->h_pinned, need + need / 4, hipHostMallocDefault));
-        c->h_pinned_cap = need + need / 4;
-    }
-    float* host = (float*)c->h_pinned;
     float* d_tris = (float*)c->d_tris.p;
     for (int k = 0; k < K; k++) {
         const uint64_t t_lo = Tb[k], t_n = Tb[k + 1] - Tb[k];
@@ -2534,41 +2651,17 @@ int project_download_write(dcsg_ctx* c, int steps, const char* stl_path, const c
             }
         }
         HIPCHK(c, hipEventRecord(c->chunk_ready[k], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->chunk_ready[k], 0));
-        if (t_n) HIPCHK(c, hipMemcpyAsync(host + t_lo * 9, d_tris + t_lo * 9, (size_t)t_n * 9 * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream));
-        HIPCHK(c, hipEventRecord(c->chunk_done[k], c->copy_stream));
     }
-    double t_last_chunk = 0;
-    auto writer = [&](const char* path, bool ply, int& rc, double& busy) {
-        const double a = now_s();
-        hipSetDevice(c->device);
-        for (int k = 0; k < K && !rc; k++) {
-            if (hipEventSynchronize(c->chunk_done[k]) != hipSuccess) {
-                rc = DCSG_ERR_HIP;
-                break;
-            }
-            if (k == K - 1 && !ply) t_last_chunk = now_s();
-            const unsigned fl = (k == 0 ? DCSG_WRITE_BEGIN : 0u) | (k == K - 1 ? DCSG_WRITE_END : 0u);
-            rc = write_range(path, host + Tb[k] * 9, Tb[k + 1] - Tb[k], Tb[k], T, fl, ply);
-        }
-        busy = now_s() - a;
-    };
-    int rc_stl = 0, rc_ply = 0;
-    double dt_stl = 0, dt_ply = 0;
-    std::thread ply_thread;
-    if (ply_path) ply_thread = std::thread([&] { writer(ply_path, true, rc_ply, dt_ply); });
-    if (stl_path) writer(stl_path, false, rc_stl, dt_stl);
-    if (ply_thread.joinable()) ply_thread.join();
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    double dt_stl = 0, dt_ply = 0, t_last = 0;
+    r = stream_triangles_to_files(c, stl_path, ply_path, 0, T, DCSG_WRITE_BEGIN | DCSG_WRITE_END, K, Tb, dt_stl, dt_ply, t_last);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // the stages overlap: t_project = until the last chunk was on the host (projection + its share of the downloads),
-    // the writers' times include their waiting for chunks
-    st.t_project = (t_last_chunk ? t_last_chunk : now_s()) - t0;
+    if (r) return r;
+    // the stages overlap: t_project = until the last piece was on the host (projection + its share of the downloads),
+    // the writers' times include their waiting for pieces
+    st.t_project = (t_last ? t_last : now_s()) - t0;
     st.t_download = 0;
     st.t_write_stl = dt_stl;
     st.t_write_ply = dt_ply;
-    if (rc_stl) return fail(c, rc_stl, "cannot write STL");
-    if (rc_ply) return fail(c, rc_ply, "cannot write PLY");
     return 0;
 }
 
@@ -2595,18 +2688,9 @@ int dcsg_write_slab(dcsg_ctx* c, const char* stl_path, const char* ply_path, uin
 {
     if (!c) return DCSG_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    float* host = nullptr;
-    int r = 0;
-    if (c->n_tris && (stl_path || ply_path) && (r = stage_triangles_on_host(c, &host))) return r;
-    int rc_stl = 0, rc_ply = 0;
-    std::thread ply_thread;
-    const uint64_t n = c->n_tris;
-    if (ply_path) ply_thread = std::thread([&] { rc_ply = dcsg_write_ply_range(ply_path, host, n, first, total, flags); });
-    if (stl_path) rc_stl = dcsg_write_stl_range(stl_path, host, n, first, total, flags);
-    if (ply_thread.joinable()) ply_thread.join();
-    if (rc_stl) return fail(c, rc_stl, "cannot write STL");
-    if (rc_ply) return fail(c, rc_ply, "cannot write PLY");
-    return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the slab's projection
+    double dt_stl = 0, dt_ply = 0, t_last = 0;
+    return stream_triangles_to_files(c, stl_path, ply_path, first, total, flags, 0, nullptr, dt_stl, dt_ply, t_last);
 }
 
 // The sharded export inside ONE process: context i (one per GPU, each with the scene loaded) runs Z slab i of n on its
@@ -2694,7 +2778,15 @@ int dcsg_export(dcsg_ctx* c, const char* cfg_txt, const char* stl_path, const ch
     HIPCHK(c, hipStreamSynchronize(c->stream));
     st.t_project = now_s() - t0;
 
-    if (stl_path || ply_path) {
+    if ((stl_path || ply_path) && !(flags & (DCSG_EXPORT_INDEXED_PLY | DCSG_EXPORT_STL_NORMALS))) {
+        double dt_stl = 0, dt_ply = 0, t_last = 0;
+        t0 = now_s();
+        if ((r = stream_triangles_to_files(c, stl_path, ply_path, 0, n_tris, DCSG_WRITE_BEGIN | DCSG_WRITE_END, 0, nullptr, dt_stl, dt_ply, t_last)))
+            return r;
+        st.t_download = (t_last ? t_last : now_s()) - t0;  // until the last piece was on the host; the writers overlap it
+        st.t_write_stl = dt_stl;
+        st.t_write_ply = dt_ply;
+    } else if (stl_path || ply_path) {  // the opt-in writers need the whole mesh at once (vertex sharing, facet normals)
         t0 = now_s();
         float* host = nullptr;
         if ((r = stage_triangles_on_host(c, &host))) return r;
