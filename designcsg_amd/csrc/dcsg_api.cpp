@@ -1365,7 +1365,8 @@ int ensure_cell_grid(dcsg_ctx* c, hipStream_t s)
     if ((r = ensure(c, c->d_cell_work, (n_all + 1) * sizeof(uint32_t)))) return r;
     // entries are handed out in chunks of 512 per wave of the build (kernels.hip DCSG_CELL_CHUNK): room for the lists and for
     // a part-used chunk per wave of a launch
-    const uint64_t capacity = std::max<uint64_t>(n_cells * 8, 4u << 20) + (uint64_t)c->n_cu * 12 * 4 * 512 + (uint64_t)c->scene.n_stack_prog;
+    uint64_t capacity = std::max<uint64_t>(n_cells * 8, 4u << 20) + (uint64_t)c->n_cu * 12 * 4 * 512 + (uint64_t)c->scene.n_stack_prog;
+    if (const char* e = getenv("DCSG_CELLS_CAPACITY")) capacity = (uint64_t)atoll(e);  // tests: start small, exercise the growth
     if ((r = ensure(c, c->d_cell_entries, capacity * sizeof(uint32_t)))) return r;
     HIPCHK(c, hipMemsetAsync(c->d_cells.p, 0xff, n_all * sizeof(uint32_t) * 2, s));  // DCSG_CELL_NOT_BUILT
     HIPCHK(c, hipMemsetAsync(c->d_cell_want.p, 0, n_cells, s));

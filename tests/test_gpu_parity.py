@@ -590,7 +590,9 @@ def test_cell_list_projection(ev, oracle, name, monkeypatch):
     with np.errstate(all="ignore"):
         for steps, n in ((1, 20_000), (9, 20_000), (50, 6_000)):
             want = osc.gradient_descent(pts[:n - n % 3].reshape(-1, 3, 3), steps).reshape(-1, 3)
-            for env in ({}, {"DCSG_CELLS": "16"}, {"DCSG_CELLS": "97", "DCSG_PROJECT_REFILL": "1"}, {"DCSG_PROJECT_REFILL": "64"}):
+            # (DCSG_CELLS_CAPACITY: the entry buffer starts far too small and has to grow while cells are being built)
+            for env in ({}, {"DCSG_CELLS": "16"}, {"DCSG_CELLS": "97", "DCSG_PROJECT_REFILL": "1"}, {"DCSG_PROJECT_REFILL": "64"},
+                        {"DCSG_CELLS": "32", "DCSG_CELLS_CAPACITY": "3000"}):
                 if steps == 50 and env:
                     continue
                 for k, v in env.items():
