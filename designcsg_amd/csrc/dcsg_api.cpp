@@ -2008,6 +2008,109 @@ int write_range(const char* path, const float* tris, uint64_t n, uint64_t first,
     return close(fd) == 0 && ok ? 0 : DCSG_ERR_IO;
 }
 
+// One output file of a streamed export (stream_triangles_to_files), held open over all its pieces: BEGIN, the
+// reservation and the mapping of this writer's byte ranges happen once, each piece is then formatted straight into the
+// mapping, END comes with close().  Calling write_range per piece instead re-opened, re-reserved and re-mapped the
+// file every time, which on a 235 MB .ply cost more than a millisecond per piece (flat256 1024^3: .ply 12.8 -> 20.1 ms
+// in six pieces).  Same bytes, same crash-safety protocol as write_range.
+class FileSink {
+public:
+    // triangles [first, first + n) of a file of `total` will be written through this sink
+    int open(const char* path, bool ply, uint64_t first, uint64_t n, uint64_t total, bool begin)
+    {
+        if (!path || first + n > total) return DCSG_ERR_INVALID;
+        if (!ply && total > 0xffffffffull) return DCSG_ERR_INVALID;
+        if (ply && total * 3 > 0xffffffffull) return DCSG_ERR_INVALID;
+        ply_ = ply, first_ = first, total_ = total;
+        if (ply) {
+            hl_ = ply_header(header_, sizeof(header_), total);
+        } else {
+            memset(header_, 0, 84);
+            uint32_t n32 = (uint32_t)total;
+            memcpy(header_ + 80, &n32, 4);
+        }
+        size_ = (off_t)hl_ + (off_t)(total * (ply ? 85 : 50));
+        fd_ = begin ? open_for_overwrite(path) : ::open(path, O_WRONLY);
+        if (fd_ < 0) return DCSG_ERR_IO;
+        if (begin) {
+            ok_ = pwrite_all(fd_, (const unsigned char*)kIncomplete, sizeof(kIncomplete) - 1, 0);
+            reserved_ = reserve_file(fd_, size_);
+        } else if (n) {
+            struct stat st;
+            reserved_ = fstat(fd_, &st) == 0 && st.st_size >= size_ && reserve_file(fd_, size_);
+        }
+        if (ok_ && n) {
+            if (ply) {
+                a_ = map_range(fd_, (off_t)hl_ + (off_t)(first * 72), (size_t)n * 72, reserved_);
+                b_ = map_range(fd_, (off_t)hl_ + (off_t)(total * 72) + (off_t)(first * 13), (size_t)n * 13, reserved_);
+                if (!a_.base || !b_.base) unmap(a_), unmap(b_);
+            } else {
+                a_ = map_range(fd_, (off_t)(84 + first * 50), (size_t)n * 50, reserved_);
+            }
+        }
+        return 0;
+    }
+    // the piece `tris` = triangles [first + at, first + at + cnt)
+    void write(const float* tris, uint64_t at, uint64_t cnt)
+    {
+        if (!ok_ || !cnt) return;
+        if (!a_.base) {  // no mapping: the buffered pwrite path of the range writers
+            ok_ = ply_ ? ply_payload(fd_, tris, cnt, first_ + at, total_, false) : stl_payload(fd_, tris, cnt, first_ + at, false);
+            return;
+        }
+        if (ply_) {
+            unsigned char *vb = a_.base + at * 72, *fb = b_.base + at * 13;
+            const uint64_t id0 = first_ + at;
+            parallel_ranges(cnt, writer_threads(), [=](uint64_t t0, uint64_t t1) {
+                unsigned char* o = vb + t0 * 72;
+                for (uint64_t i = t0 * 9; i < t1 * 9; i++, o += 8) {
+                    double v = (double)tris[i];
+                    memcpy(o, &v, 8);
+                }
+                unsigned char* q = fb + t0 * 13;
+                for (uint64_t t = id0 + t0; t < id0 + t1; t++, q += 13) {
+                    q[0] = 3;
+                    uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
+                    memcpy(q + 1, idx, 12);
+                }
+                return true;
+            });
+        } else {
+            unsigned char* base = a_.base + at * 50;
+            parallel_ranges(cnt, writer_threads(), [=](uint64_t t0, uint64_t t1) {
+                for (uint64_t t = t0; t < t1; t++) stl_record(base + t * 50, tris + t * 9);
+                return true;
+            });
+        }
+    }
+    int close(bool end)
+    {
+        if (fd_ < 0) return DCSG_ERR_IO;
+        unmap(a_);
+        unmap(b_);
+        if (ok_ && end) ok_ = ftruncate(fd_, size_) == 0 && pwrite_all(fd_, (const unsigned char*)header_, (size_t)hl_, 0);
+        if (!ok_ && ftruncate(fd_, 0) != 0) ok_ = false;
+        const bool closed = ::close(fd_) == 0;
+        fd_ = -1;
+        return closed && ok_ ? 0 : DCSG_ERR_IO;
+    }
+    ~FileSink()
+    {
+        if (fd_ >= 0) {
+            ok_ = false;
+            close(false);
+        }
+    }
+
+private:
+    int fd_ = -1, hl_ = 84;
+    bool ply_ = false, ok_ = true, reserved_ = false;
+    uint64_t first_ = 0, total_ = 0;
+    off_t size_ = 0;
+    char header_[512];
+    Mapping a_, b_;  // STL: records; PLY: vertices, faces
+};
+
 }  // namespace
 
 extern "C" {
@@ -2490,7 +2593,7 @@ int stage_triangles_on_host(dcsg_ctx* c, float** host)
 
 // The context's triangles -> stl_path / ply_path (reference layouts; either may be NULL) as triangles [first, first + n_tris)
 // of files of `total`, streamed through the pinned ring: the copy engine fills a slot while the two writers (one thread per
-// file, each formatting with its own helpers: write_range) drain earlier ones.  wflags: DCSG_WRITE_BEGIN is applied with the
+// file, each holding its file open in a FileSink) drain earlier ones.  wflags: DCSG_WRITE_BEGIN is applied with the
 // first piece, DCSG_WRITE_END with the last.  Tb / K: chunk boundaries of a pipelined projection -- a piece is downloaded
 // once the chunk holding its last triangle is projected (chunk_ready[k], recorded on the context's stream); K = 0: the
 // triangles are final (the caller has synchronised).  t_last: when the last piece was on the host.
@@ -2542,6 +2645,8 @@ int stream_triangles_to_files(dcsg_ctx* c, const char* stl_path, const char* ply
     auto writer = [&](int idx, const char* path, bool ply) {
         const double a = now_s();
         hipSetDevice(c->device);
+        FileSink sink;
+        rc_w[idx] = sink.open(path, ply, first, T, total, (wflags & DCSG_WRITE_BEGIN) != 0);
         for (uint64_t j = 0; j < n_pieces; j++) {
             {
                 std::unique_lock<std::mutex> lk(m);
@@ -2549,10 +2654,10 @@ int stream_triangles_to_files(dcsg_ctx* c, const char* stl_path, const char* ply
                 if (failed) break;
             }
             const uint64_t t_j = pieces[(size_t)j].t, n_j = pieces[(size_t)j].n;
-            if (n_j && hipEventSynchronize(c->ring_ev[j % S]) != hipSuccess) rc_w[idx] = DCSG_ERR_HIP;
+            if (!rc_w[idx] && n_j && hipEventSynchronize(c->ring_ev[j % S]) != hipSuccess) rc_w[idx] = DCSG_ERR_HIP;
             if (j + 1 == n_pieces && !ply) t_last = now_s();
-            const unsigned fl = (j == 0 ? (wflags & DCSG_WRITE_BEGIN) : 0u) | (j + 1 == n_pieces ? (wflags & DCSG_WRITE_END) : 0u);
-            if (!rc_w[idx]) rc_w[idx] = write_range(path, (const float*)(c->h_ring + (j % S) * slot_bytes), n_j, first + t_j, total, fl, ply);
+            if (!rc_w[idx]) sink.write((const float*)(c->h_ring + (j % S) * slot_bytes), t_j, n_j);
+            if (!rc_w[idx] && j + 1 == n_pieces) rc_w[idx] = sink.close((wflags & DCSG_WRITE_END) != 0);
             {
                 std::lock_guard<std::mutex> lk(m);
                 finished[(size_t)j]++;
@@ -2561,7 +2666,7 @@ int stream_triangles_to_files(dcsg_ctx* c, const char* stl_path, const char* ply
             cv.notify_all();
             if (rc_w[idx]) break;
         }
-        busy[idx] = now_s() - a;
+        busy[idx] = now_s() - a;   // a sink still open here (failure) empties its file when it goes out of scope
     };
     std::thread th_stl, th_ply;
     if (stl_path) th_stl = std::thread([&] { writer(0, stl_path, false); });
