@@ -44,7 +44,7 @@ struct DevBuf {
 // module only: needs the known Lipschitz bounds of the built-in brushes; eval_points[4] aliases [1]).
 struct Kernels {
     hipFunction_t sweep[5] = {}, eval_points[5] = {}, bbox[5] = {}, project[5] = {};
-    hipFunction_t classify = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr, test_normal = nullptr;
+    hipFunction_t classify = nullptr, complex_edges = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr, test_normal = nullptr;
     hipFunction_t set_ad_rest = nullptr;  // the rest part of a scene module has its own `arbitrary_data` pointer
     hipFunction_t sweep_d[5] = {}, sweep_f[5] = {};  // sweep[v] with the outputs fixed at compile time: SDF only / SDF + normals
     hipFunction_t sweep_nodes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // node-wise sweep per variant
@@ -113,7 +113,7 @@ struct dcsg_ctx {
     DevBuf d_blob, d_ad, d_tri_table, d_pts, d_out, d_nodes[2], d_info, d_block_sums, d_small, d_tris, d_lat_sdf,
         d_lat_nrm, d_dd_table, d_dd_rep, d_dd_slot, d_dd_compact, d_rt_keep, d_rt_out;
     // cell lists (kernels.hip "Cell lists"): built on the first projection of a many-object scene, kept until the next scene
-    DevBuf d_cells, d_cell_entries, d_cell_want, d_cell_words, d_cell_work;
+    DevBuf d_pending, d_cells, d_cell_entries, d_cell_want, d_cell_words, d_cell_work;
     DcsgCellGrid cell_grid = {};
     bool cells_valid = false;
     float cell_cover_half = 0;  // stage A's probe cube half side, when stage A came first (cell_grid_for)
@@ -239,7 +239,8 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind, int part = 
         const char* name;
         hipFunction_t* f;
         bool in_export;
-    } tab[] = {{"dcsg_mesh_classify", &k.classify, true}, {"dcsg_scan_blocks", &k.scan, true}, {"dcsg_mesh_emit", &k.emit, true},
+    } tab[] = {{"dcsg_mesh_classify", &k.classify, true}, {"dcsg_mesh_complex_edges", &k.complex_edges, true},
+               {"dcsg_scan_blocks", &k.scan, true}, {"dcsg_mesh_emit", &k.emit, true},
                {"dcsg_test_sqrt", &k.test_sqrt, false},       {"dcsg_dedup_insert", &k.dd_insert, true},
                {"dcsg_test_normal", &k.test_normal, false},
                {"dcsg_dedup_count", &k.dd_count, true},      {"dcsg_dedup_gather", &k.dd_gather, true},
@@ -688,7 +689,7 @@ void dcsg_destroy(dcsg_ctx* c)
     DevBuf* bufs[] = {&c->d_blob,  &c->d_ad,         &c->d_tri_table, &c->d_pts,  &c->d_out,     &c->d_nodes[0],
                       &c->d_nodes[1], &c->d_info,    &c->d_block_sums, &c->d_small, &c->d_tris, &c->d_lat_sdf,
                       &c->d_lat_nrm, &c->d_dd_table, &c->d_dd_rep, &c->d_dd_slot, &c->d_dd_compact, &c->d_node_mask,
-                      &c->d_rt_keep, &c->d_rt_out, &c->d_cells, &c->d_cell_entries, &c->d_cell_want, &c->d_cell_words, &c->d_cell_work};
+                      &c->d_rt_keep, &c->d_rt_out, &c->d_pending, &c->d_cells, &c->d_cell_entries, &c->d_cell_want, &c->d_cell_words, &c->d_cell_work};
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_words) hipHostFree(c->h_words);
@@ -1027,6 +1028,7 @@ int dcsg_eval_lattice(dcsg_ctx* c, const float center[3], const float diameters[
 // Stage A, DesignCSG.cpp:668-712
 namespace {
 bool slab_cut_planes(const dcsg_ctx* c, const dcsg_export_config& cfg, float center_z, float diameter, int rank, int world, int& z_lo, int& z_hi);
+int ensure_coarse_cells(dcsg_ctx* c, hipStream_t s);
 int cells_for_stage_a(dcsg_ctx* c, hipStream_t s, float probe_half);  // grid + the cells every scene has (coarse cells, the whole program)
 }
 
@@ -1189,6 +1191,16 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
     const void* blob = c->d_blob.p;
     int nv = c->scene.blob_vec4();
     const unsigned char* d_table = (const unsigned char*)c->d_tri_table.p;
+    // on-demand samples of a many-object scene read the cell lists (the coarse cells exist from here on; fine ones where
+    // earlier projections of this scene built them)
+    DcsgCellLists CL;
+    memset(&CL, 0, sizeof(CL));
+    if (c->variant == 4 && !getenv("DCSG_MESH_NO_CELLS")) {
+        if ((r = ensure_coarse_cells(c, s))) return r;
+        CL.G = c->cell_grid;
+        CL.cells = c->d_cells.p;
+        CL.entries = (const unsigned*)c->d_cell_entries.p;
+    }
     for (int level = 2; level <= cfg->max_level && n_nodes > 0; level++) {
         P.level = level;
         for (int k = 0; k < 3; k++) P.hd[k] = hd[k];
@@ -1236,18 +1248,22 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
         unsigned* d_bs = (unsigned*)c->d_block_sums.p;
         unsigned long long* d_ls = d_lstats + 4 * level;
         {
-            // the eight corner normals of a block's nodes wait in 32 KiB of LDS behind the scene's area -- where a scene of
-            // more than a thousand objects leaves that room; otherwise the kernel samples per edge end (corner_off = -1)
-            size_t lds = (c->scene.lds_bytes() + 15) & ~(size_t)15;
-            const size_t corner_bytes = (size_t)8 * 4 * DCSG_BLOCK * sizeof(float);
-            int corner_off = -1;
-            if (lds + corner_bytes + 256 <= c->max_lds && !getenv("DCSG_CLASSIFY_NO_LDS_NORMALS")) {
-                corner_off = (int)lds;
-                lds += corner_bytes;
-            }
+            // pending[0] = nodes waiting for the complex-edge test, then the nodes (kernels.hip, dcsg_mesh_complex_edges)
+            if ((r = ensure(c, c->d_pending, ((size_t)n_nodes + 1) * sizeof(unsigned)))) return r;
+            unsigned* d_pending = (unsigned*)c->d_pending.p;
+            HIPCHK(c, hipMemsetAsync(d_pending, 0, sizeof(unsigned), s));
+            const size_t lds = c->scene.lds_bytes();
             void* args[] = {(void*)&blob, &nv, &P, (void*)&d_nodes, &n_nodes, (void*)&d_sdf, (void*)&d_normals,
-                            (void*)&d_table, (void*)&d_info, (void*)&d_bs, (void*)&d_ls, &corner_off};
+                            (void*)&d_table, (void*)&d_info, (void*)&d_bs, (void*)&d_ls, (void*)&d_pending, &CL};
             if ((r = launch(c, c->k->classify, n_blocks, DCSG_BLOCK, lds, s, args))) return r;
+            if (level >= cfg->min_level && level != cfg->max_level) {  // the levels whose nodes can reach that test
+                // a wave per eight pending nodes; their number stays on the device: as many waves as could be needed, at
+                // most the chip's fill
+                const unsigned blocks = std::min<unsigned>((n_nodes + 31) / 32, (unsigned)c->n_cu * 8u);
+                void* cargs[] = {(void*)&blob, &nv, &P, (void*)&d_nodes, (void*)&d_pending, (void*)&d_normals, (void*)&d_table,
+                                 (void*)&d_info, (void*)&d_bs, (void*)&d_ls, &CL};
+                if ((r = launch(c, c->k->complex_edges, blocks, DCSG_BLOCK, lds, s, cargs))) return r;
+            }
         }
         {
             void* args[] = {(void*)&d_bs, &n_blocks, (void*)&d_totals};
@@ -1430,13 +1446,19 @@ int build_wanted_cells(dcsg_ctx* c, hipStream_t s)
     return fail(c, DCSG_ERR_HIP, "cell lists: the entry count kept growing");
 }
 
-int cells_for_stage_a(dcsg_ctx* c, hipStream_t s, float probe_half)
+// The grid and the cells every scene has from the start: the coarse cells and the pseudo-cell of the whole program
+int ensure_coarse_cells(dcsg_ctx* c, hipStream_t s)
 {
-    if (!c->cells_valid) c->cell_cover_half = std::fabs(probe_half) * 1.001f;
     const bool fresh = !c->cells_valid;
     int r = ensure_cell_grid(c, s);
     if (r) return r;
-    return fresh ? build_wanted_cells(c, s) : 0;  // the coarse cells and the pseudo-cell are wanted from the start
+    return fresh ? build_wanted_cells(c, s) : 0;  // they are wanted from the start
+}
+
+int cells_for_stage_a(dcsg_ctx* c, hipStream_t s, float probe_half)
+{
+    if (!c->cells_valid) c->cell_cover_half = std::fabs(probe_half) * 1.001f;
+    return ensure_coarse_cells(c, s);
 }
 
 // Projection through the cell lists: many-object scenes of built-in brushes (variant 4).  The cells the vertices start in
@@ -2471,11 +2493,11 @@ int export_mesh_stage(dcsg_ctx* c, const dcsg_export_config& cfg, int rank, int 
     const size_t n1 = (size_t)res + 1, plane = n1 * n1, n_pts = n1 * plane;
     const size_t slab_pts = (size_t)(z_own_hi - z_own_lo + 1) * plane;  // own planes + the shared upper one
     st.lattice_points = n_pts;
-    // Normals: swept densely with the SDF, or evaluated on demand by the mesher (its samples go through the generic
-    // interpreter, which visits every object).  Many-object scenes that run the culling kernels sweep densely:
-    // flat256 at 512^3 meshes in 0.8 ms after a 9.5 ms fused sweep instead of 37 ms after a 6 ms SDF sweep.
+    // Normals: evaluated on demand by the mesher (the few nodes that reach the complex-edge test: a wave each,
+    // dcsg_mesh_complex_edges), or swept densely with the SDF on request.  (Rounds 1-3 swept them densely for many-object
+    // scenes, whose on-demand samples then visited every object: DCSG_DENSE_NORMALS=1 brings that back for comparison.)
     const bool dense_normals = (flags & DCSG_EXPORT_DENSE_NORMALS) != 0 ||
-                               (c->variant == 4 && !(flags & DCSG_EXPORT_SPARSE_NORMALS));
+                               (c->variant == 4 && getenv("DCSG_DENSE_NORMALS") && !(flags & DCSG_EXPORT_SPARSE_NORMALS));
     // DCSG_DEBUG_LATTICE_GUARD=<bytes>: diagnostic.  The slab buffers get that many bytes of a known pattern in front and
     // behind, checked after the sweep and the mesher: a kernel that stores outside the slab's planes fails the export
     // instead of silently corrupting a neighbouring allocation (tests/test_gpu_fullsize.py runs the slab exports with it).

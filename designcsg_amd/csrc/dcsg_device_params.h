@@ -57,6 +57,13 @@ struct DcsgCellGrid {
     int g;
 };
 
+// What a kernel outside the cell-list section needs to read them (the mesher's on-demand samples)
+struct DcsgCellLists {
+    DcsgCellGrid G;
+    const void* cells;            // uint2 per cell: {first entry, count}; NULL: the scene has no cell lists
+    const unsigned int* entries;
+};
+
 struct DcsgCamera {  // kernel k1's campos / right / up / forward buffers (k1.cl:481-486)
     float o[3], r[3], u[3], f[3];
 };

@@ -1947,156 +1947,169 @@ __device__ __forceinline__ float sample_sdf(const Sampler& S, const float p[3])
 #endif
 }
 
-__device__ __forceinline__ void sample_normal(const Sampler& S, const float p[3], float n[3])
-{
-    const DcsgLattice& L = S.P->lat;
-    int ix = dcsg_snap(L, 0, p[0]), iy = dcsg_snap(L, 1, p[1]), iz = dcsg_snap(L, 2, p[2]);
-    if (S.P->has_normals && iz >= S.P->z_lo && iz <= S.P->z_hi && dcsg_lattice_point_written(*S.P, ix, iy, iz)) {
-        size_t n1 = (size_t)L.res + 1;
-        const float* q = S.nrm + (((size_t)(iz - S.P->z_lo) * n1 + iy) * n1 + ix) * 3;
-        n[0] = q[0];
-        n[1] = q[1];
-        n[2] = q[2];
-        return;
-    }
-#ifdef DCSG_HAVE_SPEC
-    float sd;
-    dcsg_stencil_spec<true>(dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy), dcsg_lattice_coord(L, 2, iz), false, true,
-                            sd, n[0], n[1], n[2]);
-#else
-    dcsg_get_normal(*S.scene, dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy),
-                    dcsg_lattice_coord(L, 2, iz), n[0], n[1], n[2]);
-#endif
-}
-
 // Node codes in info[i] (low byte; lookup case in the high byte)
 #define NODE_SKIP 0u       // culled (mesh.hpp:170) or outside this rank's Z-slab
 #define NODE_SUBDIVIDE 1u  // 8 children go to the next level
 #define NODE_LEAF 2u       // emits trsMap[lookup] triangles
 #define NODE_LEAF_REMOTE 3u  // leaf whose triangles another rank emits
 
+// primary_sdf at a point the lattice does not hold, for the lanes that `need` it; called by ALL lanes of a wave (the cell
+// lists' interpreter runs the wave as long as its longest list).  Many-object scenes of built-in brushes (CL.cells != NULL:
+// interpreter 4) read the list of the cell the point is in, as the projection does -- a handful of entries instead of
+// every object of the scene; other scenes take their module's evaluation.
+#ifdef DCSG_HAVE_CULL
+template <int N>
+__device__ __forceinline__ void dcsg_interp_lanes(const SceneLds& s, const unsigned int* __restrict__ entries, unsigned int first,
+                                                  unsigned int count, float x, float y, float z, float (&out)[N]);
+__device__ __forceinline__ uint2 dcsg_cell_list_at(const DcsgCellLists& CL, float x, float y, float z);
+#endif
+__device__ __forceinline__ float dcsg_point_sdf(const SceneLds& scene, const DcsgCellLists& CL, bool need, float x, float y, float z)
+{
+#ifdef DCSG_HAVE_CULL
+    if (CL.cells) {  // kernel argument: uniform
+        const uint2 cl = need ? dcsg_cell_list_at(CL, x, y, z) : make_uint2(0u, 0u);
+        float o[1];
+        dcsg_interp_lanes<1>(scene, CL.entries, cl.x, cl.y, x, y, z, o);
+        return o[0];
+    }
+#endif
+    float sd = 0.0f;
+    if (need) {
+#ifdef DCSG_HAVE_SPEC
+        float u0, u1, u2;
+        dcsg_stencil_spec<false>(x, y, z, true, false, sd, u0, u1, u2);
+#else
+        sd = dcsg_primary_sdf(scene, x, y, z);
+#endif
+    }
+    return sd;
+}
+
+// get_normal at such a point (k2.cl:149-179), same calling rule
+__device__ __forceinline__ void dcsg_point_normal(const SceneLds& scene, const DcsgCellLists& CL, bool need, float x, float y, float z,
+                                                  float& nx, float& ny, float& nz)
+{
+#ifdef DCSG_HAVE_CULL
+    if (CL.cells) {  // the cell's list serves the stencil too: cells are built over their box widened by epsilon
+        const uint2 cl = need ? dcsg_cell_list_at(CL, x, y, z) : make_uint2(0u, 0u);
+        float o[7];
+        dcsg_interp_lanes<7>(scene, CL.entries, cl.x, cl.y, x, y, z, o);
+        dcsg_finish_normal(o[1] - o[2], o[3] - o[4], o[5] - o[6], nx, ny, nz);
+        return;
+    }
+#endif
+    nx = ny = nz = 0.0f;
+    if (need) {
+#ifdef DCSG_HAVE_SPEC
+        float sd;
+        dcsg_stencil_spec<true>(x, y, z, false, true, sd, nx, ny, nz);
+#else
+        dcsg_get_normal(scene, x, y, z, nx, ny, nz);
+#endif
+    }
+}
+
 #ifdef DCSG_PART_EXPORT
 // Node classification.  block_sums[2*b+0] = children of block b, [2*b+1] = triangles of
 // block b.  level_stats: {culled, subdivided, leaves, triangles}, integer atomics, counting
 // only nodes this rank owns so that per-rank stats add up to the single-GPU ones.
+// The complex-edge test (mesh.hpp:244-258) is NOT made here: a node that reaches it is filed as the leaf it is unless that
+// test says otherwise, and listed in pending[1 ..] (pending[0] = count; entry = node | owned << 31) for
+// dcsg_mesh_complex_edges, which runs between this kernel and the scan.
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P, const float* __restrict__ nodes,
                    unsigned int n_nodes, const float* __restrict__ sdf, const float* __restrict__ nrm,
                    const unsigned char* __restrict__ tri_table, unsigned short* __restrict__ info,
-                   unsigned int* __restrict__ block_sums, unsigned long long* __restrict__ level_stats, int corner_off)
+                   unsigned int* __restrict__ block_sums, unsigned long long* __restrict__ level_stats,
+                   unsigned int* __restrict__ pending, DcsgCellLists CL)
 {
     SceneLds scene = dcsg_stage_scene(blob, n_vec4);
-    // [corner][x, y, z, length][thread]: 32 KiB of the dynamic allocation behind the scene's area, at byte `corner_off`;
-    // -1 when a scene with more than a thousand objects leaves no room for it (the edge test then samples per edge end)
-    float* corner_normals = corner_off >= 0 ? reinterpret_cast<float*>(reinterpret_cast<char*>(dcsg_lds) + corner_off) : nullptr;
     Sampler S = {&P, sdf, nrm, &scene};
     unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x;
     unsigned int code = NODE_SKIP, lookup = 0, n_tri = 0;
-    bool owned = false, culled = false;
+    bool owned = false, culled = false, intersects = false, pend = false;
+    float c[3] = {0.0f, 0.0f, 0.0f};
     if (i < n_nodes) {
-        float c[3] = {nodes[(size_t)i * 3 + 0], nodes[(size_t)i * 3 + 1], nodes[(size_t)i * 3 + 2]};
+        c[0] = nodes[(size_t)i * 3 + 0], c[1] = nodes[(size_t)i * 3 + 1], c[2] = nodes[(size_t)i * 3 + 2];
         // Z-slab ownership: the node's plane range [zlo, zhi]
         int zlo = dcsg_snap(P.lat, 2, c[2] + 1.0f * (P.hd[2] * -1.0f));
         int zhi = dcsg_snap(P.lat, 2, c[2] + 1.0f * (P.hd[2] * 1.0f));
-        bool intersects = zlo < P.z_own_hi && zhi > P.z_own_lo;
+        intersects = zlo < P.z_own_hi && zhi > P.z_own_lo;
         owned = zlo >= P.z_own_lo && zlo < P.z_own_hi;
-        if (intersects) {
-            // mesh.hpp:167-170
-            float d = sample_sdf(S, c);
-            float mag = dcsg_sqrt(P.hd[0] * P.hd[0] + P.hd[1] * P.hd[1] + P.hd[2] * P.hd[2]);
-            culled = __builtin_fabsf(d) > mag * 1.1f;
-            if (!culled) {
-                // mesh.hpp:176-183; the corner case is only ever used by a leaf, and a node above the minimum level
-                // is always subdivided (mesh.hpp:214-217), so its corners are not sampled
-                if (P.level >= P.min_level) {
-                    // rolled: one copy of the (per-scene, possibly large) evaluation code instead of eight -- the scene
-                    // module is compiled when a scene is first loaded, and this kernel was the largest part of that
+    }
+    // mesh.hpp:167-170: the value at the (snapped) centre.  The first levels' centres, and those of the nodes the sweep
+    // level drops, are not in a node-wise lattice: those are evaluated, the whole wave together (dcsg_point_sdf)
+    float d = 0.0f;
+    {
+        const DcsgLattice& L = P.lat;
+        const int ix = dcsg_snap(L, 0, c[0]), iy = dcsg_snap(L, 1, c[1]), iz = dcsg_snap(L, 2, c[2]);
+        const bool held = intersects && iz >= P.z_lo && iz <= P.z_hi && dcsg_lattice_point_written(P, ix, iy, iz);
+        if (held) {
+            const size_t n1 = (size_t)L.res + 1;
+            d = sdf[((size_t)(iz - P.z_lo) * n1 + iy) * n1 + ix];
+        }
+        const float e = dcsg_point_sdf(scene, CL, intersects && !held, dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy),
+                                       dcsg_lattice_coord(L, 2, iz));
+        if (!held) d = e;
+    }
+    if (intersects) {
+        float mag = dcsg_sqrt(P.hd[0] * P.hd[0] + P.hd[1] * P.hd[1] + P.hd[2] * P.hd[2]);
+        culled = __builtin_fabsf(d) > mag * 1.1f;
+        if (!culled) {
+            // mesh.hpp:176-183; the corner case is only ever used by a leaf, and a node above the minimum level
+            // is always subdivided (mesh.hpp:214-217), so its corners are not sampled
+            if (P.level >= P.min_level) {
+                // rolled: one copy of the (per-scene, possibly large) evaluation code instead of eight -- the scene
+                // module is compiled when a scene is first loaded, and this kernel was the largest part of that
 #pragma unroll 1
-                    for (int k = 0; k < 8; k++) {
-                        float p[3];
-                        dcsg_corner(k, 1.0f, c, P.hd, p);
-                        lookup |= (sample_sdf(S, p) < 0.0f ? 1u : 0u) << k;
-                    }
-                }
-                bool subdivide = false;
-                if (P.level < P.min_level) {  // mesh.hpp:214-217
-                    subdivide = true;
-                } else if (P.level != P.max_level) {  // at max level the tests cannot change the outcome (:265-267)
-                    // edge ambiguity, mesh.hpp:221-238
-                    int n_along = 1 << (P.grid_level - P.level);
-                    for (int e = 0; e < 12 && !subdivide; e++) {
-                        float a[3], b[3];
-                        dcsg_corner(dcsg_edge_a(e), 1.0f, c, P.hd, a);
-                        dcsg_corner(dcsg_edge_b(e), 1.0f, c, P.hd, b);
-                        float dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
-                        for (int j = 1; j < n_along; j++) {
-                            float f = (float)j / (float)n_along;
-                            float t[3] = {a[0] + f * dx, a[1] + f * dy, a[2] + f * dz};
-                            if (sample_sdf(S, t) < 0.0f) {
-                                subdivide = true;
-                                break;
-                            }
-                        }
-                    }
-                    // complex edges, mesh.hpp:244-258 (angleBetweenVectors, geometry.hpp:118-124).  The reference samples
-                    // the normal at both ends of each of the 12 edges; those are the 8 corners, three times each, so
-                    // they are sampled once (an on-demand normal is six evaluations of the scene).
-                    if (!subdivide) {
-                        // the corner loop is rolled (one copy of the evaluation code, see above); the eight normals and
-                        // their lengths wait in LDS, slot-major so that every access is conflict-free.  Without the LDS
-                        // area the same call site serves the 24 edge ends in turn (a: even k, b: odd k), as the
-                        // reference's loop does: three times the samples, no storage.
-                        const bool lds_normals = corner_normals != nullptr;  // block-uniform
-                        float pa[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                        auto edge_test = [&](float ax, float ay, float az, float al, float bx, float by, float bz, float bl) {
-                            float mm = al * bl;
-                            if (!(mm < 1e-6f)) {
-                                float q = (ax * bx + ay * by + az * bz) / mm;
-                                // (float)acos((double)q) > threshold, folded by the host into q_star
-                                if (q >= -1.0f && q <= P.q_star) subdivide = true;
-                            }
-                        };
-#pragma unroll 1
-                        for (int k = 0; k < (lds_normals ? 8 : 24); k++) {
-                            float p[3], n[3];
-                            const int corner = lds_normals ? k : ((k & 1) ? dcsg_edge_b(k >> 1) : dcsg_edge_a(k >> 1));
-                            dcsg_corner(corner, 1.0f, c, P.hd, p);
-                            sample_normal(S, p, n);
-                            const float len = dcsg_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                            if (lds_normals) {
-                                float* o = corner_normals + (size_t)k * 4 * DCSG_BLOCK + threadIdx.x;
-                                o[0] = n[0];
-                                o[DCSG_BLOCK] = n[1];
-                                o[2 * DCSG_BLOCK] = n[2];
-                                o[3 * DCSG_BLOCK] = len;
-                            } else if (k & 1) {
-                                edge_test(pa[0], pa[1], pa[2], pa[3], n[0], n[1], n[2], len);
-                            } else {
-                                pa[0] = n[0], pa[1] = n[1], pa[2] = n[2], pa[3] = len;
-                            }
-                        }
-                        if (lds_normals) {
-#pragma unroll 1
-                            for (int e = 0; e < 12; e++) {
-                                const float* a = corner_normals + (size_t)dcsg_edge_a(e) * 4 * DCSG_BLOCK + threadIdx.x;
-                                const float* b = corner_normals + (size_t)dcsg_edge_b(e) * 4 * DCSG_BLOCK + threadIdx.x;
-                                edge_test(a[0], a[DCSG_BLOCK], a[2 * DCSG_BLOCK], a[3 * DCSG_BLOCK], b[0], b[DCSG_BLOCK], b[2 * DCSG_BLOCK],
-                                          b[3 * DCSG_BLOCK]);
-                            }
-                        }
-                    }
-                }
-                if (subdivide) {
-                    code = NODE_SUBDIVIDE;
-                } else if (owned) {
-                    code = NODE_LEAF;
-                    n_tri = tri_table[lookup * 16];
-                } else {
-                    code = NODE_LEAF_REMOTE;
+                for (int k = 0; k < 8; k++) {
+                    float p[3];
+                    dcsg_corner(k, 1.0f, c, P.hd, p);
+                    lookup |= (sample_sdf(S, p) < 0.0f ? 1u : 0u) << k;
                 }
             }
+            bool subdivide = false;
+            if (P.level < P.min_level) {  // mesh.hpp:214-217
+                subdivide = true;
+            } else if (P.level != P.max_level) {  // at max level the tests cannot change the outcome (:265-267)
+                // edge ambiguity, mesh.hpp:221-238
+                int n_along = 1 << (P.grid_level - P.level);
+                for (int e = 0; e < 12 && !subdivide; e++) {
+                    float a[3], b[3];
+                    dcsg_corner(dcsg_edge_a(e), 1.0f, c, P.hd, a);
+                    dcsg_corner(dcsg_edge_b(e), 1.0f, c, P.hd, b);
+                    float dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+                    for (int j = 1; j < n_along; j++) {
+                        float f = (float)j / (float)n_along;
+                        float t[3] = {a[0] + f * dx, a[1] + f * dy, a[2] + f * dz};
+                        if (sample_sdf(S, t) < 0.0f) {
+                            subdivide = true;
+                            break;
+                        }
+                    }
+                }
+                pend = !subdivide;  // complex edges, mesh.hpp:244-258: dcsg_mesh_complex_edges
+            }
+            if (subdivide) {
+                code = NODE_SUBDIVIDE;
+            } else if (owned) {
+                code = NODE_LEAF;
+                n_tri = tri_table[lookup * 16];
+            } else {
+                code = NODE_LEAF_REMOTE;
+            }
         }
-        info[i] = (unsigned short)(code | (lookup << 8));
+    }
+    if (i < n_nodes) info[i] = (unsigned short)(code | (lookup << 8));
+    {   // the nodes the complex-edge test has to see, in any order (its verdict on a node does not depend on the others)
+        const unsigned long long pm = __builtin_amdgcn_ballot_w64(pend);
+        if (pm != 0ull) {
+            const unsigned int lane = threadIdx.x & (DCSG_WAVE - 1u);
+            unsigned int base = 0u;
+            if (lane == (unsigned int)__builtin_ctzll(pm)) base = atomicAdd(pending, (unsigned int)__popcll(pm));
+            base = (unsigned int)__shfl((int)base, __builtin_ctzll(pm), DCSG_WAVE);
+            if (pend) pending[1u + base + (unsigned int)__popcll(pm & ((1ull << lane) - 1ull))] = i | (owned ? 0x80000000u : 0u);
+        }
     }
     // block totals for the compaction scan + per-level statistics
     unsigned int child = code == NODE_SUBDIVIDE ? 8u : 0u;
@@ -2129,6 +2142,79 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
         if (sb) atomicAdd(&level_stats[1], (unsigned long long)sb);
         if (l) atomicAdd(&level_stats[2], (unsigned long long)l);
         if (t) atomicAdd(&level_stats[3], (unsigned long long)t);
+    }
+}
+
+// Complex edges, mesh.hpp:244-258 (angleBetweenVectors, geometry.hpp:118-124): a node without an ambiguous edge is still
+// subdivided when the surface normals at the two ends of one of its edges differ by more than the threshold.  The ends are
+// the node's 8 corners, and a normal that the lattice does not hold is six evaluations of the scene: 48 per node, for the
+// nodes that get this far -- scattered over the level, so that inside dcsg_mesh_classify (rounds 1-3) a wave ran the eight
+// corners one after the other for as few as one of its 64 nodes while the rest of the launch had long finished.  Here the
+// pending nodes are dense: a wave takes eight of them, a lane ONE corner of one node (lane = 8 * node + corner), and the 12
+// edge tests are made by the node's eight lanes exchanging normals (lane k: edge k, and edge 8 + k for k < 4).  Same
+// points, same arithmetic, same verdict as the reference's loop.  A node found complex becomes NODE_SUBDIVIDE and the sums
+// dcsg_mesh_classify wrote for it as a leaf are taken back (integer atomics: any order gives the same totals).
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_mesh_complex_edges(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P, const float* __restrict__ nodes,
+                        const unsigned int* __restrict__ pending, const float* __restrict__ nrm,
+                        const unsigned char* __restrict__ tri_table, unsigned short* __restrict__ info,
+                        unsigned int* __restrict__ block_sums, unsigned long long* __restrict__ level_stats, DcsgCellLists CL)
+{
+    SceneLds scene = dcsg_stage_scene(blob, n_vec4);
+    const unsigned int lane = threadIdx.x & (DCSG_WAVE - 1u);
+    const unsigned int waves = DCSG_BLOCK / DCSG_WAVE;
+    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / DCSG_WAVE));
+    const unsigned int n_pending = pending[0];
+    const DcsgLattice& L = P.lat;
+    const unsigned int slot = lane >> 3, group0 = lane & ~7u;
+    const int k = (int)(lane & 7u);
+    for (unsigned int w0 = (blockIdx.x * waves + wave) * 8u; w0 < n_pending; w0 += gridDim.x * waves * 8u) {
+        const bool live = w0 + slot < n_pending;
+        const unsigned int ent = pending[1u + (live ? w0 + slot : w0)], i = ent & 0x7fffffffu;
+        const bool owned = (ent >> 31) != 0u;
+        const float c[3] = {nodes[(size_t)i * 3 + 0], nodes[(size_t)i * 3 + 1], nodes[(size_t)i * 3 + 2]};
+        float p[3];
+        dcsg_corner(k, 1.0f, c, P.hd, p);
+        // the normal AT THE SNAPPED corner (ISV3D64::getValue semantics, as for the SDF); read where the lattice holds normals
+        const int ix = dcsg_snap(L, 0, p[0]), iy = dcsg_snap(L, 1, p[1]), iz = dcsg_snap(L, 2, p[2]);
+        const bool held = P.has_normals && iz >= P.z_lo && iz <= P.z_hi && dcsg_lattice_point_written(P, ix, iy, iz);
+        float nx, ny, nz;
+        dcsg_point_normal(scene, CL, live && !held, dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy), dcsg_lattice_coord(L, 2, iz), nx,
+                          ny, nz);
+        if (held) {
+            const size_t n1 = (size_t)L.res + 1;
+            const float* q = nrm + (((size_t)(iz - P.z_lo) * n1 + iy) * n1 + ix) * 3;
+            nx = q[0], ny = q[1], nz = q[2];
+        }
+        const float len = dcsg_sqrt(nx * nx + ny * ny + nz * nz);
+        // edge e joins corners a(e) and b(e) (mesh.hpp:187-209): a(e) = e for the two rings, a(8 + j) = j for the verticals
+        auto edge_test = [&](int other) {
+            const int from = (int)group0 + other;
+            const float bx = __shfl(nx, from, DCSG_WAVE), by = __shfl(ny, from, DCSG_WAVE), bz = __shfl(nz, from, DCSG_WAVE),
+                        bl = __shfl(len, from, DCSG_WAVE);
+            const float mm = len * bl;
+            if (mm < 1e-6f) return false;
+            const float q = (nx * bx + ny * by + nz * bz) / mm;
+            // (float)acos((double)q) > threshold, folded by the host into q_star
+            return q >= -1.0f && q <= P.q_star;
+        };
+        bool complex_edge = edge_test(dcsg_edge_b(k));
+        const bool vertical = edge_test(k < 4 ? dcsg_edge_b(8 + k) : k);
+        complex_edge = complex_edge || (k < 4 && vertical);
+        const unsigned long long votes = __builtin_amdgcn_ballot_w64(live && complex_edge);
+        if (live && k == 0 && ((votes >> group0) & 0xffull) != 0ull) {
+            const unsigned int lookup = (unsigned int)info[i] >> 8;
+            info[i] = (unsigned short)(NODE_SUBDIVIDE | (lookup << 8));
+            const unsigned int b = i / DCSG_BLOCK;
+            atomicAdd(&block_sums[2u * b], 8u);
+            if (owned) {  // it was counted as a leaf of this rank
+                const unsigned int n_tri = tri_table[lookup * 16u];
+                atomicSub(&block_sums[2u * b + 1u], n_tri);
+                atomicAdd(&level_stats[1], 1ull);
+                atomicAdd(&level_stats[2], ~0ull);  // - 1
+                atomicAdd(&level_stats[3], 0ull - (unsigned long long)n_tri);
+            }
+        }
     }
 }
 
@@ -2687,6 +2773,19 @@ __device__ __forceinline__ unsigned int dcsg_cell_of(const DcsgCellGrid& G, floa
     if (!inside) return g * g * g;
     ix = (unsigned int)fx, iy = (unsigned int)fy, iz = (unsigned int)fz;
     return (iz * g + iy) * g + ix;
+}
+
+// The list that serves a point: its fine cell where that is built, else the coarse cell around it (all of those exist), the
+// whole program outside the cube.
+__device__ __forceinline__ uint2 dcsg_cell_list_at(const DcsgCellLists& CL, float x, float y, float z)
+{
+    const unsigned int g = (unsigned int)CL.G.g, n_cells = g * g * g, gc = g / DCSG_CELL_COARSE;
+    unsigned int cx = 0u, cy = 0u, cz = 0u;
+    const unsigned int cell = dcsg_cell_of(CL.G, x, y, z, cx, cy, cz);
+    const uint2* cells = reinterpret_cast<const uint2*>(CL.cells);
+    uint2 cl = cells[cell];
+    if (cl.y == DCSG_CELL_NOT_BUILT) cl = cells[n_cells + 1u + ((cz / DCSG_CELL_COARSE) * gc + cy / DCSG_CELL_COARSE) * gc + cx / DCSG_CELL_COARSE];
+    return cl;
 }
 
 // Cells are built where vertices are: want[cell] = 1 asks for a cell, 2 = built.  The cells of the vertices and their 26
