@@ -565,10 +565,23 @@ int sweep_device(dcsg_ctx* c, const float center[3], const float diam[3], int re
         unsigned cnt = (unsigned)(np * plane);
         unsigned work = cnt;
         unsigned per_block = 4u * DCSG_BLOCK;  // a block covers 4 runs of 256 points per pass (dcsg_sweep_body)
-        if (c->variant == 4) {  // 8 x 8 x 4 bricks, one per 256-thread block iteration
-            uint64_t b8 = (n1 + 7) / 8;
-            work = (unsigned)(b8 * b8 * ((np + 3) / 4) * DCSG_BLOCK);
+        if (c->variant == 4) {
+            // one brick per 256-thread block iteration (kernels.hip, dcsg_sweep_c4_body): 16 x 16 x 8 points; 8 x 8 x 8 for
+            // scenes with smooth joins, where a longer list costs more than building it less often saves.  Measured at
+            // 513^3, fused / SDF only, ms (profiles/r04_brick_shapes.txt):   8x8x4 (rounds 1-3)  8x8x8   16x16x4  16x16x8
+            //   flat256     4.20 / 3.34    3.23 / 2.29    3.72 / 2.29    3.53 / 2.03
+            //   grouped256 12.89 / 10.70   9.42 / 7.07    9.57 / 6.33    8.90 / 5.47
+            //   smooth256  17.93 / 12.00  16.02 / 9.61   19.37 / 10.47  19.09 / 9.90
+            // DCSG_BRICK=<wide 0|1>,<depth> overrides (measurements).
+            int wide = c->scene.has_smooth ? 0 : 1, depth = 8;
+            if (const char* e = getenv("DCSG_BRICK")) {
+                int w = 1, d = 8;
+                if (sscanf(e, "%d,%d", &w, &d) == 2 && d >= 1 && d <= 64 && (w || d % 4 == 0)) wide = w ? 1 : 0, depth = d;
+            }
+            const uint64_t side = wide ? 16 : 8, bs = (n1 + side - 1) / side;
+            work = (unsigned)(bs * bs * ((np + depth - 1) / depth) * DCSG_BLOCK);
             per_block = DCSG_BLOCK;
+            axes_off = depth | (wide << 8);
         }
         unsigned tiles = (work + per_block - 1) / per_block;
         void* args[] = {(void*)&blob, &nv, &L, &z0, &first, &cnt, (void*)&d_sdf, (void*)&d_nrm, &axes_off, &flags};

@@ -2539,32 +2539,42 @@ __device__ __forceinline__ int dcsg_build_block_list(const SceneLds& s, int n_ve
 }
 
 // Lattice sweep with block-brick culling.  The launch covers whole planes (first = multiple of (res+1)^2).
-// A wave writes 8 rows of 8 consecutive points (32-B / 96-B segments): this kernel is for scenes whose cost
-// is hundreds of object evaluations per point, where store shape is irrelevant next to the work removed.
+// A block owns a brick of lattice points: ONE list for the brick (every thread bounds one item, dcsg_build_block_list), then
+// passes of 256 points each.  `shape` = depth | wide << 8:
+//   wide    16 x 16 x depth: a pass is a z plane of the brick (thread = (x, y); a wave writes 4 rows of 16 consecutive points:
+//           64-B / 192-B segments);
+//   narrow   8 x  8 x depth (a multiple of 4): a pass is 8 x 8 x 4 (a wave writes 8 rows of 8 points).
+// Rounds 1-3 built a list per 8 x 8 x 4 brick, i.e. per 256 points: bounding the scene's items cost as much as evaluating
+// what was left of them (flat256: ~400 of 1 100 vector instructions per point).  A brick of 2 048 points pays for its list
+// an eighth as often, and the list of a brick twice as wide is hardly longer where objects are many times the size of a
+// brick; where every extra entry is dear (smooth joins with normals: the blend radius widens every bound) the host keeps
+// the small brick (dcsg_api.cpp, sweep_device).
 // MODE as in dcsg_sweep_body: 0 = outputs read off the pointers, 1 = SDF only, 3 = SDF + normals (own kernel names, so
 // that a profile never averages the 4 B/point and the 16 B/point sweep under one name)
 template <int MODE>
 __device__ __forceinline__ void dcsg_sweep_c4_body(const uint4* __restrict__ blob, int n_vec4, const DcsgLattice& L, int z0, unsigned int first,
-                                                   unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_arg)
+                                                   unsigned int n_points, float* __restrict__ sdf_out, float* __restrict__ nrm_arg, int shape)
 {
     float* __restrict__ nrm_out = MODE == 1 ? nullptr : nrm_arg;
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
+    const bool wide = (shape >> 8) != 0;                                          // kernel argument: uniform
+    const unsigned int side = wide ? 16u : 8u, depth = (unsigned int)(shape & 0xff), pass_planes = wide ? 1u : 4u;
     const unsigned int n1 = (unsigned int)L.res + 1u;
     const unsigned int plane = n1 * n1;
     const unsigned int planes = dcsg_div_n1(L, dcsg_div_n1(L, n_points));
     const unsigned int first_plane = dcsg_div_n1(L, dcsg_div_n1(L, first));
-    const unsigned int bx = (n1 + 7u) >> 3, by = (n1 + 7u) >> 3, bz = (planes + 3u) >> 2;
+    const unsigned int bx = (n1 + side - 1u) / side, by = bx, bz = (planes + depth - 1u) / depth;
     const unsigned int bricks = bx * by * bz;
     const float pad = nrm_out ? (float)K2_NORMAL_EPSILON * 1.01f : 0.0f;
-    const unsigned int lx = threadIdx.x & 7u, ly = (threadIdx.x >> 3) & 7u, lz = threadIdx.x >> 6;
+    const unsigned int lx = threadIdx.x & (side - 1u), ly = wide ? threadIdx.x >> 4 : (threadIdx.x >> 3) & 7u, lz = wide ? 0u : threadIdx.x >> 6;
     for (unsigned int brick = blockIdx.x; brick < bricks; brick += gridDim.x) {
         unsigned int tx = brick % bx, t2 = brick / bx;
         unsigned int ty = t2 % by, tz = t2 / by;
         // brick bounds in lattice indices (clipped) -> centre and radius in world units
-        unsigned int ix0 = tx * 8u, iy0 = ty * 8u, izl0 = tz * 4u;
-        unsigned int ix1 = ix0 + 7u < n1 - 1u ? ix0 + 7u : n1 - 1u;
-        unsigned int iy1 = iy0 + 7u < n1 - 1u ? iy0 + 7u : n1 - 1u;
-        unsigned int izl1 = izl0 + 3u < planes - 1u ? izl0 + 3u : planes - 1u;
+        unsigned int ix0 = tx * side, iy0 = ty * side, izl0 = tz * depth;
+        unsigned int ix1 = ix0 + side - 1u < n1 - 1u ? ix0 + side - 1u : n1 - 1u;
+        unsigned int iy1 = iy0 + side - 1u < n1 - 1u ? iy0 + side - 1u : n1 - 1u;
+        unsigned int izl1 = izl0 + depth - 1u < planes - 1u ? izl0 + depth - 1u : planes - 1u;
         float xa = dcsg_lattice_coord(L, 0, (int)ix0), xb = dcsg_lattice_coord(L, 0, (int)ix1);
         float ya = dcsg_lattice_coord(L, 1, (int)iy0), yb = dcsg_lattice_coord(L, 1, (int)iy1);
         float za = dcsg_lattice_coord(L, 2, (int)(first_plane + izl0) + z0);
@@ -2575,23 +2585,27 @@ __device__ __forceinline__ void dcsg_sweep_c4_body(const uint4* __restrict__ blo
         const unsigned short* list;
         int n_list = dcsg_build_block_list(s, n_vec4, 0.5f * (xa + xb), 0.5f * (ya + yb), 0.5f * (za + zb), R, list);
 
-        unsigned int ix = ix0 + lx, iy = iy0 + ly, izl = izl0 + lz;
-        bool valid = ix < n1 && iy < n1 && izl < planes;
+        const unsigned int ix = ix0 + lx, iy = iy0 + ly;
+        const bool valid_xy = ix < n1 && iy < n1;
         // invalid lanes evaluate a clamped point (keeps the wave's control flow uniform) and store nothing
-        unsigned int cix = ix < n1 ? ix : n1 - 1u, ciy = iy < n1 ? iy : n1 - 1u, cizl = izl < planes ? izl : planes - 1u;
-        float x = dcsg_lattice_coord(L, 0, (int)cix);
-        float y = dcsg_lattice_coord(L, 1, (int)ciy);
-        float z = dcsg_lattice_coord(L, 2, (int)(first_plane + cizl) + z0);
-        float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
-        dcsg_stencil<4>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz, list, n_list);
-        if (valid) {
-            unsigned int idx = first + izl * plane + iy * n1 + ix;
-            if (sdf_out) sdf_out[idx] = sd;
-            if (nrm_out) {
-                float* o = nrm_out + (size_t)idx * 3;
-                o[0] = nx;
-                o[1] = ny;
-                o[2] = nz;
+        const unsigned int cix = ix < n1 ? ix : n1 - 1u, ciy = iy < n1 ? iy : n1 - 1u;
+        const float x = dcsg_lattice_coord(L, 0, (int)cix);
+        const float y = dcsg_lattice_coord(L, 1, (int)ciy);
+#pragma unroll 1
+        for (unsigned int pz = izl0; pz <= izl1; pz += pass_planes) {  // block-uniform bounds
+            const unsigned int izl = pz + lz, cizl = izl < planes ? izl : planes - 1u;
+            const float z = dcsg_lattice_coord(L, 2, (int)(first_plane + cizl) + z0);
+            float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
+            dcsg_stencil<4>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz, list, n_list);
+            if (valid_xy && izl <= izl1) {
+                unsigned int idx = first + izl * plane + iy * n1 + ix;
+                if (sdf_out) sdf_out[idx] = sd;
+                if (nrm_out) {
+                    float* o = nrm_out + (size_t)idx * 3;
+                    o[0] = nx;
+                    o[1] = ny;
+                    o[2] = nz;
+                }
             }
         }
     }
@@ -2606,9 +2620,10 @@ __device__ __forceinline__ void dcsg_sweep_c4_body(const uint4* __restrict__ blo
 #define DCSG_SWEEP_C4_KERNEL(NAME, MODE)                                                                               \
     extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, ((MODE) == 1 ? DCSG_C4D_WAVES : DCSG_C4_WAVES))         \
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, int z0, unsigned int first, unsigned int n_points, \
-         float* __restrict__ sdf_out, float* __restrict__ nrm_out, int /*axes_off: unused*/, unsigned int /*flags*/)   \
+         float* __restrict__ sdf_out, float* __restrict__ nrm_out, int shape /*axes_off of the other sweeps*/,          \
+         unsigned int /*flags*/)                                                                                        \
     {                                                                                                                  \
-        dcsg_sweep_c4_body<MODE>(blob, n_vec4, L, z0, first, n_points, sdf_out, nrm_out);                              \
+        dcsg_sweep_c4_body<MODE>(blob, n_vec4, L, z0, first, n_points, sdf_out, nrm_out, shape);                       \
     }
 DCSG_SWEEP_C4_KERNEL(dcsg_sweep_c4, 0)
 DCSG_SWEEP_C4_KERNEL(dcsg_sweep_c4_d, 1)
