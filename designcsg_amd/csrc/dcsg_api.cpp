@@ -1230,10 +1230,17 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             // level 2, children of parents that straddle slabs) are skipped by the kernel
             int zo_lo = z_own_lo, zo_hi = z_own_hi;
             unsigned* d_swept = (unsigned*)((char*)c->d_small.p + 2048);  // zeroed with d_small above
+            // culling scenes: one list per eight sibling nodes (kernels.hip, dcsg_sweep_nodes_c4; the other kernels do not
+            // read the argument).  Measured, sweep ms with a list per node / per eight: flat256 1024^3 2.0 / 1.1, 512^3 0.6 /
+            // 0.4; grouped256 6.0 / 3.3, 1.6 / 1.3; smooth256 10.9 / 9.3 but 3.0 / 3.5 at 512^3 -- with smooth joins the
+            // blend radius widens every bound, and a box of eight coarse nodes keeps too much: those scenes group only
+            // from level 7 on (nodes of 1/128 of the box).
+            int group = (c->variant == 4 && n_nodes % 8 == 0 && (!c->scene.has_smooth || level >= 7) && !getenv("DCSG_NODE_GROUP_1")) ? 8 : 1;
             void* args[] = {(void*)&blob, &nv, &P.lat, (void*)&d_list, &n_nodes, &sh, &lvl, (void*)&ns->d_sdf, (void*)&ns->d_nrm,
-                            (void*)&d_mask, &P.hd[0], &P.hd[1], &P.hd[2], &zo_lo, &zo_hi, (void*)&d_swept};
+                            (void*)&d_mask, &P.hd[0], &P.hd[1], &P.hd[2], &zo_lo, &zo_hi, (void*)&d_swept, &group};
             HIPCHK(c, hipEventRecord(c->ev0, s));
-            if ((r = launch(c, c->k->sweep_nodes[c->variant], n_nodes, DCSG_BLOCK, c->scene.lds_bytes(), s, args))) return r;
+            if ((r = launch(c, c->k->sweep_nodes[c->variant], (n_nodes + group - 1) / group, DCSG_BLOCK, c->scene.lds_bytes(), s, args)))
+                return r;
             HIPCHK(c, hipEventRecord(c->ev1, s));
             unsigned& swept = *(unsigned*)c->h_words;
             HIPCHK(c, hipMemcpyAsync(&swept, d_swept, sizeof(swept), hipMemcpyDeviceToHost, s));
