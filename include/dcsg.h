@@ -202,7 +202,7 @@ int dcsg_parse_export_config(const char* export_config_txt, dcsg_export_config* 
  * mesher, retopologize (identity), projection, both writers.
  * stl_path / ply_path may be NULL to skip a writer.  flags: DCSG_EXPORT_*. */
 #define DCSG_EXPORT_DENSE_NORMALS 1u  /* sweep normals for every lattice point instead of on demand */
-#define DCSG_EXPORT_SPARSE_NORMALS 2u /* never sweep normals densely (default: dense only for culled scenes) */
+#define DCSG_EXPORT_SPARSE_NORMALS 2u /* normals on demand: the default (kept for callers of rounds 1-3, when culled scenes swept densely) */
 #define DCSG_EXPORT_DENSE_SWEEP 16u   /* sweep the whole lattice even where the node-wise sweep would do */
 #define DCSG_EXPORT_INDEXED_PLY 4u    /* ply_path gets dcsg_write_ply_indexed instead of the reference layout */
 #define DCSG_EXPORT_STL_NORMALS 8u    /* stl_path gets dcsg_write_stl_normals instead of zero normals */

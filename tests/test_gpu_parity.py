@@ -919,8 +919,8 @@ def test_set_arbitrary_data_after_build(ev, oracle):
 def test_large_object_tables(built_lib, oracle, lookup_table, monkeypatch):
     """Beyond the reference's MAX_OBJECTS 512 / MAX_BUILD_STEPS 256 (DrawPane.h:14-15): the tables live in LDS, so
     ~1400 objects fit (160 KiB); more is refused with a clear error instead of overflowing.  The 1200-object scene also
-    EXPORTS: its tables leave no room for the mesher's 32 KiB of corner normals in LDS, and dcsg_mesh_classify then
-    samples the normals per edge end (same mesh: checked against the oracle, and on a small scene against the LDS form)."""
+    EXPORTS (the mesher's kernels take no LDS beyond the scene's own area), the mesh checked against the oracle with the
+    on-demand samples through the cell lists, through the whole program, and with normals read from a dense sweep."""
     from designcsg_amd import _lib
     from designcsg_amd.evaluator import Evaluator
     rng = np.random.default_rng(0)
@@ -951,17 +951,15 @@ def test_large_object_tables(built_lib, oracle, lookup_table, monkeypatch):
         want = osc.gradient_descent(raw, 3)
         assert stats.triangles == len(want) > 1000
         assert np.array_equal(sorted_tris(e.download_triangles()), sorted_tris(want))
-        # the per-edge-end form against the LDS form on a scene that has room for both
-        s2 = read_scene("design1")
-        meshes = []
-        for off in (False, True):
-            if off:
-                monkeypatch.setenv("DCSG_CLASSIFY_NO_LDS_NORMALS", "1")
-            assert e.build(s2["scene.txt"], s2["buildprocedure.txt"], s2["scene.cl"])[0] == 0
-            e.export(export_config_text("design1", levels=(3, 6, 7), gd=2))
-            meshes.append(sorted_tris(e.download_triangles()))
-        monkeypatch.delenv("DCSG_CLASSIFY_NO_LDS_NORMALS")
-        assert len(meshes[0]) > 1000 and np.array_equal(meshes[0], meshes[1])
+        # the mesher's on-demand samples of such a scene read the cell lists; the same mesh without them (every sample runs the
+        # whole program) and with densely swept normals (the complex-edge test then reads the lattice)
+        for env, dense in (("DCSG_MESH_NO_CELLS", False), (None, True)):
+            if env:
+                monkeypatch.setenv(env, "1")
+            assert e.export(cfg_txt, dense_normals=dense).triangles == len(want)
+            assert np.array_equal(sorted_tris(e.download_triangles()), sorted_tris(want))
+            if env:
+                monkeypatch.delenv(env)
         st, bp = scene(2400)
         with pytest.raises(_lib.DcsgError) as ei:
             e.build(st, bp, None)
