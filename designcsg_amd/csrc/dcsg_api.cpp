@@ -50,7 +50,7 @@ struct Kernels {
     hipFunction_t sweep_nodes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // node-wise sweep per variant
     hipFunction_t dd_insert = nullptr, dd_resolve = nullptr, dd_count = nullptr, dd_gather = nullptr, dd_scatter = nullptr;  // vertex dedup
     hipFunction_t rt_mark = nullptr, rt_count = nullptr, rt_emit = nullptr;  // opt-in retopologize
-    hipFunction_t bbox_cells = nullptr, cells_mark = nullptr, cells_collect = nullptr, cells_build = nullptr, project_cells = nullptr;  // cell lists of many-object scenes (built-in module)
+    hipFunction_t cells_mark = nullptr, cells_collect = nullptr, cells_build = nullptr, project_cells = nullptr;  // cell lists of many-object scenes (built-in module)
 };
 
 double now_s()
@@ -116,7 +116,6 @@ struct dcsg_ctx {
     DevBuf d_pending, d_cells, d_cell_entries, d_cell_want, d_cell_words, d_cell_work;
     DcsgCellGrid cell_grid = {};
     bool cells_valid = false;
-    float cell_cover_half = 0;  // stage A's probe cube half side, when stage A came first (cell_grid_for)
     double cells_built_ms = 0;  // host-side time spent building cells of the loaded scene so far (launch to completion)
     uint64_t cell_entries = 0, cells_built = 0;
     // stage A's by-product for the Z-slab cuts: probes with |sdf| < one probe spacing per probe plane z = half_neg + cd (k - 128)
@@ -257,7 +256,6 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind, int part = 
         HIPCHK(c, hipModuleGetFunction(&k.bbox[4], mod, "dcsg_bbox_c4"));
         k.project[4] = nullptr;  // culling scenes project through the cell lists (project_cells)
         HIPCHK(c, hipModuleGetFunction(&k.cells_mark, mod, "dcsg_cells_mark"));
-        HIPCHK(c, hipModuleGetFunction(&k.bbox_cells, mod, "dcsg_bbox_cells"));
         HIPCHK(c, hipModuleGetFunction(&k.cells_collect, mod, "dcsg_cells_collect"));
         HIPCHK(c, hipModuleGetFunction(&k.cells_build, mod, "dcsg_cells_build"));
         HIPCHK(c, hipModuleGetFunction(&k.project_cells, mod, "dcsg_project_cells"));
@@ -898,7 +896,6 @@ int dcsg_load_scene(dcsg_ctx* c, const char* scene_txt, const char* bp_txt, cons
     }
     c->scene_loaded = true;
     c->cells_valid = false;
-    c->cell_cover_half = 0;
     c->n_tris = 0;
     c->scene_cl_text = scene_cl ? scene_cl : "";
     if (c->preview_mod) {  // belongs to the previous scene
@@ -1042,7 +1039,6 @@ int dcsg_eval_lattice(dcsg_ctx* c, const float center[3], const float diameters[
 namespace {
 bool slab_cut_planes(const dcsg_ctx* c, const dcsg_export_config& cfg, float center_z, float diameter, int rank, int world, int& z_lo, int& z_hi);
 int ensure_coarse_cells(dcsg_ctx* c, hipStream_t s);
-int cells_for_stage_a(dcsg_ctx* c, hipStream_t s, float probe_half);  // grid + the cells every scene has (coarse cells, the whole program)
 }
 
 int dcsg_estimate_bounding_box(dcsg_ctx* c, float bb_half, float center[3], float* diameter, uint64_t* interior)
@@ -1062,16 +1058,7 @@ int dcsg_estimate_bounding_box(dcsg_ctx* c, float bb_half, float center[3], floa
     int nv = c->scene.blob_vec4();
     float cdv = cd, hnv = half_neg;
     int* res_ptr = (int*)c->d_small.p;
-    if (c->variant == 4 && !c->scene.has_smooth && !getenv("DCSG_BBOX_WAVE_LISTS")) {
-        // culling scenes: the probes read the cell lists (coarse cells on a scene's first export, the fine ones the
-        // projection built afterwards): flat256 1.0 -> 0.6 ms, grouped256 2.1 -> 1.7; not with smooth joins, whose coarse
-        // lists are long (smooth256 2.2 -> 2.5: they keep the per-wave lists of dcsg_bbox_c4)
-        if ((r = cells_for_stage_a(c, c->stream, 0.5f * bb_half))) return r;
-        const void* cells = c->d_cells.p;
-        const void* entries = c->d_cell_entries.p;
-        void* cargs[] = {(void*)&blob, &nv, &cdv, &hnv, &bb_eps, (void*)&res_ptr, (void*)&c->cell_grid, (void*)&cells, (void*)&entries};
-        if ((r = launch(c, c->kb.bbox_cells, (unsigned)c->n_cu * 16u, DCSG_BLOCK, c->scene.lds_bytes(), c->stream, cargs))) return r;
-    } else {
+    {
         void* args[] = {(void*)&blob, &nv, &cdv, &hnv, &bb_eps, (void*)&res_ptr};
         if ((r = launch(c, c->k->bbox[c->variant], (unsigned)c->n_cu * 16u, DCSG_BLOCK, c->scene.lds_bytes(), c->stream, args)))
             return r;
@@ -1345,12 +1332,10 @@ namespace {
 // The cube the cell lists cover: every object's bounding sphere (its brush lives in [-0.5, 0.5]^3 of the local frame,
 // whose axes are the reciprocals of the stored vectors, scenecompiler.py:538-541), a twentieth more.  Vertices outside
 // it are still projected correctly (the pseudo-cell of the whole program), only slowly.
-DcsgCellGrid cell_grid_for(const Scene& sc, int g, float cover_half)
+DcsgCellGrid cell_grid_for(const Scene& sc, int g)
 {
-    // cover_half > 0: the cube also covers [-cover_half, cover_half]^3 (stage A's probe cube: a probe outside the cells
-    // would run the whole program)
-    float lo[3] = {-cover_half, -cover_half, -cover_half}, hi[3] = {cover_half, cover_half, cover_half};
-    bool any = cover_half > 0;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    bool any = false;
     for (int o = 0; o < sc.n_objects; o++) {
         if (sc.shape[o] <= 1) continue;  // null / void brushes have no surface
         double r2 = 0;
@@ -1392,7 +1377,7 @@ int ensure_cell_grid(dcsg_ctx* c, hipStream_t s)
     const char* eg = getenv("DCSG_CELLS");
     int g = eg ? atoi(eg) : 128;  // measured 32 .. 256 on the 256-brush scenes at 512^3 and 1024^3: 128 is the fastest, cold and warm
     g = (g < 4 ? 4 : (g > 256 ? 256 : g)) & ~3;  // a coarse cell is 4 x 4 x 4 fine ones
-    c->cell_grid = cell_grid_for(c->scene, g, c->cell_cover_half);
+    c->cell_grid = cell_grid_for(c->scene, g);
     const uint64_t n_cells = (uint64_t)g * g * g, n_coarse = n_cells / 64, n_all = n_cells + 1 + n_coarse;
     int r;
     if ((r = ensure(c, c->d_cells, n_all * sizeof(uint32_t) * 2))) return r;
@@ -1475,11 +1460,6 @@ int ensure_coarse_cells(dcsg_ctx* c, hipStream_t s)
     return fresh ? build_wanted_cells(c, s) : 0;  // they are wanted from the start
 }
 
-int cells_for_stage_a(dcsg_ctx* c, hipStream_t s, float probe_half)
-{
-    if (!c->cells_valid) c->cell_cover_half = std::fabs(probe_half) * 1.001f;
-    return ensure_coarse_cells(c, s);
-}
 
 // Projection through the cell lists: many-object scenes of built-in brushes (variant 4).  The cells the vertices start in
 // (and their neighbours) are built first, together with whatever earlier projections of this scene asked for; a vertex that

@@ -2629,37 +2629,52 @@ DCSG_SWEEP_C4_KERNEL(dcsg_sweep_c4, 0)
 DCSG_SWEEP_C4_KERNEL(dcsg_sweep_c4_d, 1)
 DCSG_SWEEP_C4_KERNEL(dcsg_sweep_c4_f, 3)
 
+// Stage A of a culling scene with per-wave lists: a wave takes bricks of 8 x 8 x 8 probes -- ONE list for the brick's box, then
+// eight passes of 4 x 4 x 4 probes (rounds 1-3: a list per 64 probes; bounding the scene's items was most of the kernel).
+// The result does not depend on the visiting order.
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, double bb_eps, int* __restrict__ result)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     DCSG_BBOX_ZHIST_DECL
     unsigned short* list = dcsg_wave_list(s, n_vec4);
-    const unsigned int total = 256u * 256u * 256u;  // a multiple of the block size: every lane is valid
+    const unsigned int lane = threadIdx.x & (DCSG_WAVE - 1u), waves = DCSG_BLOCK / DCSG_WAVE;
+    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / DCSG_WAVE));
     int mn[3] = {1 << 20, 1 << 20, 1 << 20};
     int mx[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
     unsigned int cnt = 0;
-    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < total; i += gridDim.x * DCSG_BLOCK) {
-        // a wave's 64 consecutive probes form a 4 x 4 x 4 brick (the result does not depend on the visiting order)
-        int iz = (int)((((i >> 6) & 63u) << 2) | (i & 3u)) - 128;
-        int iy = (int)((((i >> 12) & 63u) << 2) | ((i >> 2) & 3u)) - 128;
-        int ix = (int)(((i >> 18) << 2) | ((i >> 4) & 3u)) - 128;
-        float x = half_neg + cd * (float)ix;
-        float y = half_neg + cd * (float)iy;
-        float z = half_neg + cd * (float)iz;
-        int n_list = dcsg_build_active_list(s, true, x, y, z, 0.0f, list);
-        float v, u0, u1, u2;
-        dcsg_stencil<4>(s, x, y, z, true, false, v, u0, u1, u2, list, n_list);
-        if ((double)__builtin_fabsf(v) < bb_eps) atomicAdd(&zh[iz + 128], 1u);
-        if ((double)v < bb_eps) {
-            cnt++;
-            mn[0] = ix < mn[0] ? ix : mn[0];
-            mx[0] = ix > mx[0] ? ix : mx[0];
-            mn[1] = iy < mn[1] ? iy : mn[1];
-            mx[1] = iy > mx[1] ? iy : mx[1];
-            mn[2] = iz < mn[2] ? iz : mn[2];
-            mx[2] = iz > mx[2] ? iz : mx[2];
+    for (unsigned int brick = blockIdx.x * waves + wave; brick < 32u * 32u * 32u; brick += gridDim.x * waves) {
+        const int bx = (int)(brick & 31u) * 8 - 128, by = (int)((brick >> 5) & 31u) * 8 - 128, bz = (int)(brick >> 10) * 8 - 128;
+        // the box of the brick's probes, from the probes' own coordinates (the same expressions as below: monotone in the index)
+        const float x0 = half_neg + cd * (float)bx, x1 = half_neg + cd * (float)(bx + 7);
+        const float y0 = half_neg + cd * (float)by, y1 = half_neg + cd * (float)(by + 7);
+        const float z0 = half_neg + cd * (float)bz, z1 = half_neg + cd * (float)(bz + 7);
+        const int n_list = dcsg_build_active_list_box(s, 0.5f * (x0 + x1), 0.5f * (y0 + y1), 0.5f * (z0 + z1), 0.5f * __builtin_fabsf(x1 - x0),
+                                                      0.5f * __builtin_fabsf(y1 - y0), 0.5f * __builtin_fabsf(z1 - z0), list);
+#pragma unroll 1
+        for (unsigned int pass = 0u; pass < 8u; pass++) {
+            const int ix = bx + (int)((pass & 1u) * 4u + (lane & 3u));
+            const int iy = by + (int)(((pass >> 1) & 1u) * 4u + ((lane >> 2) & 3u));
+            const int iz = bz + (int)((pass >> 2) * 4u + (lane >> 4));
+            float x = half_neg + cd * (float)ix;
+            float y = half_neg + cd * (float)iy;
+            float z = half_neg + cd * (float)iz;
+            float v, u0, u1, u2;
+            dcsg_stencil<4>(s, x, y, z, true, false, v, u0, u1, u2, list, n_list);
+            if ((double)__builtin_fabsf(v) < bb_eps) atomicAdd(&zh[iz + 128], 1u);
+            if ((double)v < bb_eps) {
+                cnt++;
+                mn[0] = ix < mn[0] ? ix : mn[0];
+                mx[0] = ix > mx[0] ? ix : mx[0];
+                mn[1] = iy < mn[1] ? iy : mn[1];
+                mx[1] = iy > mx[1] ? iy : mx[1];
+                mn[2] = iz < mn[2] ? iz : mn[2];
+                mx[2] = iz > mx[2] ? iz : mx[2];
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the list area is rewritten by the next brick
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     dcsg_bbox_commit(mn, mx, cnt, result, zh);
 }
@@ -3108,48 +3123,6 @@ dcsg_project_cells(const uint4* __restrict__ blob, int n_vec4, float* __restrict
     }
 }
 
-// Stage A of a culling scene over the cell lists: the 256^3 probes in bricks of 4 x 4 x 4 per wave as dcsg_bbox_c4 takes them,
-// each lane reading the list of the cell ITS probe is in -- the fine cell where an earlier projection built it, the coarse
-// cell around it otherwise (all of those exist), the whole program outside the cube -- instead of every wave bounding all
-// the scene's items for its 64 probes.  Same values, same reduction.
-extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
-dcsg_bbox_cells(const uint4* __restrict__ blob, int n_vec4, float cd, float half_neg, double bb_eps, int* __restrict__ result,
-                DcsgCellGrid G, const uint2* __restrict__ cells, const unsigned int* __restrict__ entries)
-{
-    SceneLds s = dcsg_stage_scene(blob, n_vec4);
-    DCSG_BBOX_ZHIST_DECL
-    const unsigned int total = 256u * 256u * 256u;  // a multiple of the block size: every lane is valid
-    const unsigned int g = (unsigned int)G.g, n_cells = g * g * g, gc = g / DCSG_CELL_COARSE;
-    int mn[3] = {1 << 20, 1 << 20, 1 << 20};
-    int mx[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
-    unsigned int cnt = 0;
-    for (unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x; i < total; i += gridDim.x * DCSG_BLOCK) {
-        int iz = (int)((((i >> 6) & 63u) << 2) | (i & 3u)) - 128;
-        int iy = (int)((((i >> 12) & 63u) << 2) | ((i >> 2) & 3u)) - 128;
-        int ix = (int)(((i >> 18) << 2) | ((i >> 4) & 3u)) - 128;
-        float x = half_neg + cd * (float)ix;
-        float y = half_neg + cd * (float)iy;
-        float z = half_neg + cd * (float)iz;
-        unsigned int cx = 0u, cy = 0u, cz = 0u;
-        const unsigned int cell = dcsg_cell_of(G, x, y, z, cx, cy, cz);
-        uint2 cl = cells[cell];
-        if (cl.y == DCSG_CELL_NOT_BUILT) cl = cells[n_cells + 1u + ((cz / DCSG_CELL_COARSE) * gc + cy / DCSG_CELL_COARSE) * gc + cx / DCSG_CELL_COARSE];
-        float o[1];
-        dcsg_interp_lanes<1>(s, entries, cl.x, cl.y, x, y, z, o);
-        const float v = o[0];
-        if ((double)__builtin_fabsf(v) < bb_eps) atomicAdd(&zh[iz + 128], 1u);
-        if ((double)v < bb_eps) {
-            cnt++;
-            mn[0] = ix < mn[0] ? ix : mn[0];
-            mx[0] = ix > mx[0] ? ix : mx[0];
-            mn[1] = iy < mn[1] ? iy : mn[1];
-            mx[1] = iy > mx[1] ? iy : mx[1];
-            mn[2] = iz < mn[2] ? iz : mn[2];
-            mx[2] = iz > mx[2] ? iz : mx[2];
-        }
-    }
-    dcsg_bbox_commit(mn, mx, cnt, result, zh);
-}
 #endif  // DCSG_PART_EXPORT (cell lists)
 #endif
 
