@@ -1146,6 +1146,7 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
     P.has_normals = d_normals ? 1 : 0;
     P.z_own_lo = z_own_lo;
     P.z_own_hi = z_own_hi;
+    P.mask_check = getenv("DCSG_MESH_MASK_ALWAYS") ? 1 : 0;
     P.use_spec = c->specialised ? 1 : 0;  // informational: a module of the specialised set samples through its per-scene code
 
     // mesh.hpp:110-125: levels 0 and 1 are subdivided unconditionally; the 64 level-2 nodes start the
@@ -1249,10 +1250,11 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
         }
         unsigned n_blocks = (n_nodes + DCSG_BLOCK - 1) / DCSG_BLOCK;
         if ((r = ensure(c, c->d_info, (size_t)n_nodes * sizeof(unsigned short)))) return r;
-        if ((r = ensure(c, c->d_block_sums, (size_t)n_blocks * 2 * sizeof(unsigned)))) return r;
+        if ((r = ensure(c, c->d_block_sums, (size_t)n_blocks * 5 * sizeof(unsigned)))) return r;  // {children, triangles}, then {culled, subdivided, leaves} per block
         const float* d_nodes = (const float*)c->d_nodes[cur].p;
         unsigned short* d_info = (unsigned short*)c->d_info.p;
         unsigned* d_bs = (unsigned*)c->d_block_sums.p;
+        unsigned* d_bstats = d_bs + (size_t)n_blocks * 2;
         unsigned long long* d_ls = d_lstats + 4 * level;
         {
             // pending[0] = nodes waiting for the complex-edge test, then the nodes (kernels.hip, dcsg_mesh_complex_edges)
@@ -1261,19 +1263,19 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             HIPCHK(c, hipMemsetAsync(d_pending, 0, sizeof(unsigned), s));
             const size_t lds = c->scene.lds_bytes();
             void* args[] = {(void*)&blob, &nv, &P, (void*)&d_nodes, &n_nodes, (void*)&d_sdf, (void*)&d_normals,
-                            (void*)&d_table, (void*)&d_info, (void*)&d_bs, (void*)&d_ls, (void*)&d_pending, &CL};
+                            (void*)&d_table, (void*)&d_info, (void*)&d_bs, (void*)&d_bstats, (void*)&d_pending, &CL};
             if ((r = launch(c, c->k->classify, n_blocks, DCSG_BLOCK, lds, s, args))) return r;
             if (level >= cfg->min_level && level != cfg->max_level) {  // the levels whose nodes can reach that test
                 // a wave per eight pending nodes; their number stays on the device: as many waves as could be needed, at
                 // most the chip's fill
                 const unsigned blocks = std::min<unsigned>((n_nodes + 31) / 32, (unsigned)c->n_cu * 8u);
                 void* cargs[] = {(void*)&blob, &nv, &P, (void*)&d_nodes, (void*)&d_pending, (void*)&d_normals, (void*)&d_table,
-                                 (void*)&d_info, (void*)&d_bs, (void*)&d_ls, &CL};
+                                 (void*)&d_info, (void*)&d_bs, (void*)&d_bstats, &CL};
                 if ((r = launch(c, c->k->complex_edges, blocks, DCSG_BLOCK, lds, s, cargs))) return r;
             }
         }
         {
-            void* args[] = {(void*)&d_bs, &n_blocks, (void*)&d_totals};
+            void* args[] = {(void*)&d_bs, &n_blocks, (void*)&d_totals, (void*)&d_bstats, (void*)&d_ls};
             if ((r = launch(c, c->k->scan, 1, 1024, 0, s, args))) return r;
         }
         unsigned* totals = (unsigned*)c->h_words;
@@ -1594,7 +1596,8 @@ int dedup_prepare(dcsg_ctx* c, hipStream_t s, Dedup& d, const unsigned* probe_bl
         if ((r = launch(c, c->k->dd_count, n_blocks, DCSG_BLOCK, 0, s, args))) return r;
     }
     {
-        void* args[] = {(void*)&bs, &n_blocks, (void*)&totals};
+        const void* no_stats = nullptr;
+        void* args[] = {(void*)&bs, &n_blocks, (void*)&totals, (void*)&no_stats, (void*)&no_stats};
         if ((r = launch(c, c->k->scan, 1, 1024, 0, s, args))) return r;
     }
     unsigned* tot = (unsigned*)c->h_words;  // pinned; the probes behind it (n_probe <= 8)
@@ -1708,7 +1711,8 @@ int dcsg_retopologize(dcsg_ctx* c, const float center[3], float diameter, int mi
         if ((r = launch(c, c->k->rt_count, n_blocks, DCSG_BLOCK, 0, s, args))) return r;
     }
     {
-        void* args[] = {(void*)&bs, (void*)&n_blocks, (void*)&totals};
+        const void* no_stats = nullptr;
+        void* args[] = {(void*)&bs, (void*)&n_blocks, (void*)&totals, (void*)&no_stats, (void*)&no_stats};
         if ((r = launch(c, c->k->scan, 1, 1024, 0, s, args))) return r;
     }
     unsigned tot[2];

@@ -39,6 +39,7 @@ struct DcsgMeshParams {
     const unsigned char* node_mask;
     int mask_level, mask_shift;
     int use_spec;  // on-demand samples through the module's per-scene specialised code (spec kernel set only)
+    int mask_check;  // diagnostic (DCSG_MESH_MASK_ALWAYS): every sample asks the node mask, also inside its own swept node
 };
 
 struct DcsgRetopo {  // T-junction repair in the spirit of cms::retopologize (mesh.hpp:432-529; oracle_retopologize)
