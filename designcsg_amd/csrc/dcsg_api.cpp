@@ -125,7 +125,7 @@ struct dcsg_ctx {
     uint64_t last_unique_vertices = 0;  // distinct positions projected by the last dcsg_project_triangles
     // pinned host words for the small read-backs (counts, totals, the bounding-box words): a copy into pageable memory goes
     // through the runtime's staging path and costs tens of microseconds more, a dozen times per export
-    unsigned char* h_words = nullptr;  // 8 KiB
+    unsigned char* h_words = nullptr;  // 32 KiB
     void* h_pinned = nullptr;  // host staging of the WHOLE triangle buffer (opt-in writers only, which need all of it at once)
     size_t h_pinned_cap = 0;
     // The reference writers stream: a ring of pinned slots that downloads fill and the two writers drain, allocated once
@@ -643,7 +643,7 @@ int dcsg_create(dcsg_ctx** out, int device_id)
     if (c->max_lds > 160 * 1024) c->max_lds = 160 * 1024;
     lap.mark("hip_runtime_and_device");
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CK(hipHostMalloc((void**)&c->h_words, 8192, hipHostMallocDefault));
+    CK(hipHostMalloc((void**)&c->h_words, 32768, hipHostMallocDefault));
     CK(hipEventCreate(&c->ev0));
     for (auto& pr : c->sweep_ev) {
         CK(hipEventCreate(&pr[0]));
@@ -1050,27 +1050,42 @@ int dcsg_estimate_bounding_box(dcsg_ctx* c, float bb_half, float center[3], floa
     volatile float cd = (float)bb_half / R;  // cube_diameter
     volatile float half_neg = -cd / 2;       // v3f(-cube_diameter / 2)
     double bb_eps = (double)((float)bb_half / R) * 1.0;  // BB_EPSILON
-    if ((r = ensure(c, c->d_small, 4096))) return r;
-    // [0..5] min / max indices, [8..9] interior count, [16..271] probes near the surface per probe plane in z
-    int seed[16 + 256] = {1 << 20, 1 << 20, 1 << 20, -(1 << 20), -(1 << 20), -(1 << 20)};
-    HIPCHK(c, hipMemcpyAsync(c->d_small.p, seed, sizeof(seed), hipMemcpyHostToDevice, c->stream));
+    // DCSG_BBOX_COPIES copies of [0..5] min / max indices, [8..9] interior count, [16..271] probes near the surface per probe
+    // plane in z (kernels.hip, dcsg_bbox_commit), reduced here
+    const size_t words = (size_t)DCSG_BBOX_WORDS * DCSG_BBOX_COPIES;
+    if ((r = ensure(c, c->d_small, std::max<size_t>(4096, words * sizeof(int))))) return r;
+    int* seed = (int*)c->h_words;  // pinned; rewritten by the read-back below, which the stream orders behind this upload
+    memset(seed, 0, words * sizeof(int));
+    for (int k = 0; k < DCSG_BBOX_COPIES; k++)
+        for (int j = 0; j < 3; j++) seed[k * DCSG_BBOX_WORDS + j] = 1 << 20, seed[k * DCSG_BBOX_WORDS + 3 + j] = -(1 << 20);
+    HIPCHK(c, hipMemcpyAsync(c->d_small.p, seed, words * sizeof(int), hipMemcpyHostToDevice, c->stream));
     const void* blob = c->d_blob.p;
     int nv = c->scene.blob_vec4();
     float cdv = cd, hnv = half_neg;
     int* res_ptr = (int*)c->d_small.p;
     {
         void* args[] = {(void*)&blob, &nv, &cdv, &hnv, &bb_eps, (void*)&res_ptr};
-        if ((r = launch(c, c->k->bbox[c->variant], (unsigned)c->n_cu * 16u, DCSG_BLOCK, c->scene.lds_bytes(), c->stream, args)))
+        const unsigned per_cu = getenv("DCSG_BBOX_BLOCKS_PER_CU") ? (unsigned)atoi(getenv("DCSG_BBOX_BLOCKS_PER_CU")) : 8u;
+        if ((r = launch(c, c->k->bbox[c->variant], (unsigned)c->n_cu * (per_cu ? per_cu : 8u), DCSG_BLOCK, c->scene.lds_bytes(), c->stream, args)))
             return r;
     }
     int* out = (int*)c->h_words;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_small.p, (16 + 256) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_small.p, words * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t cnt = 0;
+    for (int k = 1; k < DCSG_BBOX_COPIES; k++) {  // into copy 0
+        const int* o = out + k * DCSG_BBOX_WORDS;
+        for (int j = 0; j < 3; j++) out[j] = std::min(out[j], o[j]), out[3 + j] = std::max(out[3 + j], o[3 + j]);
+        for (int j = 16; j < DCSG_BBOX_WORDS; j++) out[j] = (int)((uint32_t)out[j] + (uint32_t)o[j]);
+    }
+    for (int k = 0; k < DCSG_BBOX_COPIES; k++) {
+        uint64_t part;
+        memcpy(&part, &out[k * DCSG_BBOX_WORDS + 8], 8);
+        cnt += part;
+    }
     for (int k = 0; k < 256; k++) c->probe_z_hist[k] = (uint32_t)out[16 + k];
     c->probe_cd = cd;
     c->probe_half_neg = half_neg;
-    uint64_t cnt;
-    memcpy(&cnt, &out[8], 8);
     float mn[3] = {0.0f, 0.0f, 0.0f}, mx[3] = {0.0f, 0.0f, 0.0f};  // initialised to 0.0, :688-693
     if (cnt) {
         for (int k = 0; k < 3; k++) {

@@ -4,6 +4,8 @@
 #define DCSG_DEVICE_PARAMS_H
 
 #define DCSG_BLOCK 256
+#define DCSG_BBOX_WORDS 272   // stage A's result: [0..5] min / max indices, [8..9] interior count (u64), [16..271] probes near the surface per z plane
+#define DCSG_BBOX_COPIES 16   // ... kept in that many copies (kernels.hip, dcsg_bbox_commit)
 #define DCSG_WAVE 64
 #define DCSG_MAX_SLOTS 64  /* STACK_MEMORY_PER_PIXEL, Evaluator.cpp:7 */
 /* dcsg_sweep* `flags`: bit 0 = the lattice holds no -0.0 coordinate (checked by the host), so a sweep of per-scene code
