@@ -1242,8 +1242,12 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             void* args[] = {(void*)&blob, &nv, &P.lat, (void*)&d_list, &n_nodes, &sh, &lvl, (void*)&ns->d_sdf, (void*)&ns->d_nrm,
                             (void*)&d_mask, &P.hd[0], &P.hd[1], &P.hd[2], &zo_lo, &zo_hi, (void*)&d_swept, &group};
             HIPCHK(c, hipEventRecord(c->ev0, s));
-            if ((r = launch(c, c->k->sweep_nodes[c->variant], (n_nodes + group - 1) / group, DCSG_BLOCK, c->scene.lds_bytes(), s, args)))
-                return r;
+            // blocks walk the list with a stride: as many as keep the chip full several times over, each adding its count of
+            // swept nodes once (DCSG_NODE_BLOCKS_PER_CU, 0 = a block per node or group as in rounds 1-3)
+            const unsigned per_cu = getenv("DCSG_NODE_BLOCKS_PER_CU") ? (unsigned)atoi(getenv("DCSG_NODE_BLOCKS_PER_CU")) : 64u;
+            unsigned blocks = (n_nodes + group - 1) / group;
+            if (per_cu && blocks > (unsigned)c->n_cu * per_cu) blocks = (unsigned)c->n_cu * per_cu;
+            if ((r = launch(c, c->k->sweep_nodes[c->variant], blocks, DCSG_BLOCK, c->scene.lds_bytes(), s, args))) return r;
             HIPCHK(c, hipEventRecord(c->ev1, s));
             unsigned& swept = *(unsigned*)c->h_words;
             HIPCHK(c, hipMemcpyAsync(&swept, d_swept, sizeof(swept), hipMemcpyDeviceToHost, s));

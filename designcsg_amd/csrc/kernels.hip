@@ -1576,6 +1576,7 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
     __shared__ float tab[3 * DCSG_NODE_TAB];
     const DcsgNodeGrid g = dcsg_node_grid(shift);
     const size_t n1 = (size_t)L.res + 1u;
+    unsigned int swept_here = 0u;  // block-uniform; one atomic per block at the end (one per node, all on the same word, retire one at a time)
     for (unsigned int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
         int i0[3], ic[3];
         size_t slot;
@@ -1591,10 +1592,8 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
             else dcsg_stencil<(K <= 0 ? 4 : K)>(s, cx, cy, cz, true, false, d, u0, u1, u2);
             if (dcsg_node_culled(d, hdx, hdy, hdz)) continue;
         }
-        if (threadIdx.x == 0) {
-            node_mask[slot] = 1;
-            atomicAdd(n_swept, 1u);
-        }
+        if (threadIdx.x == 0) node_mask[slot] = 1;
+        swept_here++;
         dcsg_node_axes(L, i0, g.side, tab);
         const size_t base = ((size_t)i0[2] * n1 + (size_t)i0[1]) * n1 + (size_t)i0[0];
 #ifdef DCSG_HAVE_SPEC
@@ -1645,6 +1644,7 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
             }
         }
     }
+    if (threadIdx.x == 0 && swept_here) atomicAdd(n_swept, swept_here);
 }
 
 #define DCSG_SWEEP_NODES_KERNEL(NAME, K)                                                                             \
@@ -2743,6 +2743,7 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
     const size_t n1 = (size_t)L.res + 1u;
     const float pad = nrm_out ? (float)K2_NORMAL_EPSILON * 1.01f : 0.0f;
     const unsigned int per = (unsigned int)group, n_groups = (n_nodes + per - 1u) / per;
+    unsigned int swept_here = 0u;  // block-uniform; one atomic per block at the end
     for (unsigned int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const unsigned int n_first = grp * per, n_end = n_first + per < n_nodes ? n_first + per : n_nodes;
         // the group's box in lattice indices (block-uniform: every thread reads the same nodes)
@@ -2781,10 +2782,8 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
                             true, false, d, u0, u1, u2, list, n_list);
             if (dcsg_node_culled(d, hdx, hdy, hdz)) continue;
         }
-        if (threadIdx.x == 0) {
-            node_mask[slot] = 1;
-            atomicAdd(n_swept, 1u);
-        }
+        if (threadIdx.x == 0) node_mask[slot] = 1;
+        swept_here++;
         dcsg_node_axes(L, i0, side, tab);
         const size_t base = ((size_t)i0[2] * n1 + (size_t)i0[1]) * n1 + (size_t)i0[0];
         if (!nrm_out && sdf_out) {
@@ -2833,6 +2832,7 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
         }
       }  // nodes of the group
     }
+    if (threadIdx.x == 0 && swept_here) atomicAdd(n_swept, swept_here);
 }
 
 #ifdef DCSG_PART_EXPORT
