@@ -2126,23 +2126,15 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
         }
     }
     if (i < n_nodes) info[i] = (unsigned short)(code | (lookup << 8));
-    {   // the nodes the complex-edge test has to see, in any order (its verdict on a node does not depend on the others)
-        const unsigned long long pm = __builtin_amdgcn_ballot_w64(pend);
-        if (pm != 0ull) {
-            const unsigned int lane = threadIdx.x & (DCSG_WAVE - 1u);
-            unsigned int base = 0u;
-            if (lane == (unsigned int)__builtin_ctzll(pm)) base = atomicAdd(pending, (unsigned int)__popcll(pm));
-            base = (unsigned int)__shfl((int)base, __builtin_ctzll(pm), DCSG_WAVE);
-            if (pend) pending[1u + base + (unsigned int)__popcll(pm & ((1ull << lane) - 1ull))] = i | (owned ? 0x80000000u : 0u);
-        }
-    }
-    // block totals for the compaction scan + per-level statistics
+    // block totals for the compaction scan + per-level statistics; the nodes the complex-edge test has to see
+    const unsigned long long pm = __builtin_amdgcn_ballot_w64(pend);
     unsigned int child = code == NODE_SUBDIVIDE ? 8u : 0u;
     unsigned int wc = wave_sum(child), wt = wave_sum(n_tri);
     unsigned int ws = wave_sum((owned && code == NODE_SUBDIVIDE) ? 1u : 0u);
     unsigned int wl = wave_sum(code == NODE_LEAF ? 1u : 0u);
     unsigned int wq = wave_sum((owned && culled) ? 1u : 0u);
-    __shared__ unsigned int part[5][DCSG_BLOCK / DCSG_WAVE];
+    __shared__ unsigned int part[6][DCSG_BLOCK / DCSG_WAVE];
+    __shared__ unsigned int pend_base;
     int wave = threadIdx.x / DCSG_WAVE;
     if ((threadIdx.x & (DCSG_WAVE - 1)) == 0) {
         part[0][wave] = wc;
@@ -2150,16 +2142,18 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
         part[2][wave] = wl;
         part[3][wave] = wq;
         part[4][wave] = ws;
+        part[5][wave] = (unsigned int)__popcll(pm);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned int cs = 0, t = 0, l = 0, q = 0, sb = 0;
+        unsigned int cs = 0, t = 0, l = 0, q = 0, sb = 0, np = 0;
         for (int k = 0; k < DCSG_BLOCK / DCSG_WAVE; k++) {
             cs += part[0][k];
             t += part[1][k];
             l += part[2][k];
             q += part[3][k];
             sb += part[4][k];
+            np += part[5][k];
         }
         block_sums[2 * blockIdx.x + 0] = cs;
         block_sums[2 * blockIdx.x + 1] = t;
@@ -2168,6 +2162,13 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
         block_stats[3 * blockIdx.x + 0] = q;
         block_stats[3 * blockIdx.x + 1] = sb;
         block_stats[3 * blockIdx.x + 2] = l;
+        pend_base = np ? atomicAdd(pending, np) : 0u;  // one per block, for the same reason
+    }
+    __syncthreads();
+    if (pend) {  // in any order: the test's verdict on a node does not depend on the others
+        unsigned int off = pend_base + (unsigned int)__popcll(pm & ((1ull << (threadIdx.x & (DCSG_WAVE - 1u))) - 1ull));
+        for (int k = 0; k < wave; k++) off += part[5][k];
+        pending[1u + off] = i | (owned ? 0x80000000u : 0u);
     }
 }
 
