@@ -6,9 +6,7 @@
 // every entry point fails with DCSG_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
-#include <sys/vfs.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -1872,62 +1870,6 @@ int ply_header(char* header, size_t cap, uint64_t n)
                     (unsigned long long)(n * 3), (unsigned long long)n);
 }
 
-// A shared mapping of the file range [off, off + len): the writer threads then format records straight into the page
-// cache -- no staging buffer, no second copy, and none of the per-inode serialisation that buffered pwrite()s to one
-// file meet (measured on the GPU box: the 136 MB .ply took 8-11 ms with 2, 4, 8 or 16 pwrite threads alike).
-// Only when the blocks behind the range are known to exist (`reserved`: fallocate succeeded), so that a full disk
-// surfaces as an error from fallocate and not as SIGBUS from a store.  Returns NULL when mapping is not possible; the
-// pwrite path is the fallback.
-struct Mapping {
-    unsigned char* base = nullptr;  // address of file offset `off`
-    void* map = nullptr;
-    size_t map_len = 0;
-};
-// File systems on which a successful fallocate(2) means the blocks exist (unwritten extents / resident pages), so that
-// a store into the mapping cannot meet ENOSPC and kill the process with SIGBUS: ext2/3/4, XFS, tmpfs.  overlayfs
-// forwards fallocate to its upper layer, which may be anything: there the reservation is VERIFIED -- the blocks the file
-// now occupies (st_blocks, the upper inode's) must cover its length -- before the mapping is chosen.  Anything else -- NFS,
-// FUSE, COW file systems, an overlay whose upper layer did not allocate -- takes the pwrite path, where a full disk is an
-// error return.  DCSG_WRITER_MMAP=1 forces the mapping.
-bool fs_honours_fallocate(int fd)
-{
-    if (const char* e = getenv("DCSG_WRITER_MMAP")) return atoi(e) != 0;
-    struct statfs sf;
-    if (fstatfs(fd, &sf) != 0) return false;
-    switch ((unsigned long)sf.f_type) {
-    case 0xEF53ul:      // ext2 / ext3 / ext4
-    case 0x58465342ul:  // XFS
-    case 0x01021994ul:  // tmpfs
-        return true;
-    case 0x794c7630ul: {  // overlayfs: only with the allocation in evidence
-        struct stat st;
-        return fstat(fd, &st) == 0 && st.st_size > 0 && (uint64_t)st.st_blocks * 512u >= (uint64_t)st.st_size;
-    }
-    default:
-        return false;
-    }
-}
-
-Mapping map_range(int fd, off_t off, size_t len, bool reserved)
-{
-    Mapping m;
-    if (!reserved || len == 0 || getenv("DCSG_WRITER_NO_MMAP") || !fs_honours_fallocate(fd)) return m;
-    const long page = sysconf(_SC_PAGESIZE);
-    const off_t lo = off / page * page;
-    const size_t span = (size_t)(off - lo) + len;
-    void* p = mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_SHARED, fd, lo);
-    if (p == MAP_FAILED) return m;
-    m.map = p;
-    m.map_len = span;
-    m.base = (unsigned char*)p + (off - lo);
-    return m;
-}
-void unmap(Mapping& m)
-{
-    if (m.map) munmap(m.map, m.map_len);
-    m = Mapping();
-}
-
 inline void stl_record(unsigned char* o, const float* v)
 {
     float rec[12] = {0.0f, 0.0f, 0.0f, v[0], v[2], v[1], v[3], v[5], v[4], v[6], v[8], v[7]};
@@ -1935,70 +1877,59 @@ inline void stl_record(unsigned char* o, const float* v)
     o[48] = o[49] = 0;
 }
 
+// (Rounds 2-4 carried a second path here that formatted straight into a shared mapping of the file.  It never ran: the
+// files are opened write-only and mmap refuses a shared writable mapping of such a descriptor -- every number this repo
+// ever reported came from the pwrite path below.  Measured for real this round (tools/fmt_probe.cpp, GPU box): first-touch
+// faults of a shared file mapping cost 16-25 ms for the 136 MB .ply whatever the thread count, against 7-8 ms for these
+// buffered pwrites, so the mapping is gone rather than repaired.)
+
 // STL payload of triangles [first, first + n) of a file of `total` triangles: records at 84 + 50 t
-bool stl_payload(int fd, const float* tris, uint64_t n, uint64_t first, bool reserved)
+bool stl_payload(int fd, const float* tris, uint64_t n, uint64_t first)
 {
-    Mapping m = map_range(fd, (off_t)(84 + first * 50), (size_t)n * 50, reserved);
-    if (m.base) {
-        unsigned char* base = m.base;
-        parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
-            for (uint64_t t = t0; t < t1; t++) stl_record(base + t * 50, tris + t * 9);
-            return true;
-        });
-        unmap(m);
-        return true;
-    }
     return parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
         const uint64_t step = 1u << 15;  // triangles per buffer (1.6 MB)
         std::vector<unsigned char> buf((size_t)step * 50);
         for (uint64_t a = t0; a < t1; a += step) {
             uint64_t b = a + step < t1 ? a + step : t1;
             unsigned char* o = buf.data();
-            for (uint64_t t = a; t < b; t++, o += 50) {
-                const float* v = tris + t * 9;
-                float rec[12] = {0.0f, 0.0f, 0.0f, v[0], v[2], v[1], v[3], v[5], v[4], v[6], v[8], v[7]};
-                memcpy(o, rec, 48);
-                o[48] = o[49] = 0;
-            }
+            for (uint64_t t = a; t < b; t++, o += 50) stl_record(o, tris + t * 9);
             if (!pwrite_all(fd, buf.data(), (size_t)(b - a) * 50, (off_t)(84 + (first + a) * 50))) return false;
         }
         return true;
     });
 }
 
-// PLY payload of triangles [first, first + n) of a file of `total`: vertices at hl + 72 t, faces at hl + 72 total + 13 t
-bool ply_payload(int fd, const float* tris, uint64_t n, uint64_t first, uint64_t total, bool reserved)
+// PLY face records of triangles [first, first + n) of a file of `total`: at hl + 72 total + 13 t.  They depend on nothing
+// but t.
+bool ply_faces(int fd, uint64_t n, uint64_t first, uint64_t total)
 {
     char header[512];
-    const int hl = ply_header(header, sizeof(header), total);
-    const off_t verts_at = hl, faces_at = hl + (off_t)(total * 72);
-    Mapping mv = map_range(fd, verts_at + (off_t)(first * 72), (size_t)n * 72, reserved);
-    Mapping mf = map_range(fd, faces_at + (off_t)(first * 13), (size_t)n * 13, reserved);
-    if (mv.base && mf.base) {
-        unsigned char *vb = mv.base, *fb = mf.base;
-        parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
-            unsigned char* o = vb + t0 * 72;
-            for (uint64_t i = t0 * 9; i < t1 * 9; i++, o += 8) {
-                double v = (double)tris[i];
-                memcpy(o, &v, 8);
-            }
-            unsigned char* q = fb + t0 * 13;
-            for (uint64_t t = first + t0; t < first + t1; t++, q += 13) {
+    const off_t faces_at = ply_header(header, sizeof(header), total) + (off_t)(total * 72);
+    return parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
+        const uint64_t step = 1u << 16;  // triangles per buffer (0.85 MB)
+        std::vector<unsigned char> fbuf((size_t)step * 13);
+        for (uint64_t a = t0; a < t1; a += step) {
+            uint64_t b = a + step < t1 ? a + step : t1;
+            unsigned char* q = fbuf.data();
+            for (uint64_t t = first + a; t < first + b; t++, q += 13) {
                 q[0] = 3;
                 uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
                 memcpy(q + 1, idx, 12);
             }
-            return true;
-        });
-        unmap(mv);
-        unmap(mf);
+            if (!pwrite_all(fd, fbuf.data(), (size_t)(b - a) * 13, faces_at + (off_t)((first + a) * 13))) return false;
+        }
         return true;
-    }
-    unmap(mv);
-    unmap(mf);
+    });
+}
+
+// PLY vertices of triangles [first, first + n) of a file of `total`: at hl + 72 t
+bool ply_vertices(int fd, const float* tris, uint64_t n, uint64_t first, uint64_t total)
+{
+    char header[512];
+    const off_t verts_at = ply_header(header, sizeof(header), total);
     return parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
-        const uint64_t step = 1u << 14;  // triangles per buffer (1.2 MB of vertices, 0.2 MB of faces)
-        std::vector<unsigned char> vbuf((size_t)step * 72), fbuf((size_t)step * 13);
+        const uint64_t step = 1u << 14;  // triangles per buffer (1.2 MB)
+        std::vector<unsigned char> vbuf((size_t)step * 72);
         for (uint64_t a = t0; a < t1; a += step) {
             uint64_t b = a + step < t1 ? a + step : t1;
             unsigned char* o = vbuf.data();
@@ -2006,14 +1937,7 @@ bool ply_payload(int fd, const float* tris, uint64_t n, uint64_t first, uint64_t
                 double v = (double)tris[i];
                 memcpy(o, &v, 8);
             }
-            unsigned char* q = fbuf.data();
-            for (uint64_t t = first + a; t < first + b; t++, q += 13) {
-                q[0] = 3;
-                uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
-                memcpy(q + 1, idx, 12);
-            }
             if (!pwrite_all(fd, vbuf.data(), (size_t)(b - a) * 72, verts_at + (off_t)((first + a) * 72))) return false;
-            if (!pwrite_all(fd, fbuf.data(), (size_t)(b - a) * 13, faces_at + (off_t)((first + a) * 13))) return false;
         }
         return true;
     });
@@ -2038,26 +1962,22 @@ int write_range(const char* path, const float* tris, uint64_t n, uint64_t first,
     const bool begin = (flags & DCSG_WRITE_BEGIN) != 0, end = (flags & DCSG_WRITE_END) != 0;
     int fd = begin ? open_for_overwrite(path) : open(path, O_WRONLY);
     if (fd < 0) return DCSG_ERR_IO;
-    bool ok = true, reserved = false;
+    bool ok = true;
     if (begin) {
         ok = pwrite_all(fd, (const unsigned char*)kIncomplete, sizeof(kIncomplete) - 1, 0);
-        reserved = reserve_file(fd, size);
-    } else if (n) {
-        // a later rank: BEGIN has sized the file; blocks are known to exist if its reservation can be repeated here
-        struct stat st;
-        reserved = fstat(fd, &st) == 0 && st.st_size >= size && reserve_file(fd, size);
+        reserve_file(fd, size);
     }
-    if (ok && n) ok = ply ? ply_payload(fd, tris, n, first, total, reserved) : stl_payload(fd, tris, n, first, reserved);
+    if (ok && n) ok = ply ? (ply_vertices(fd, tris, n, first, total) && ply_faces(fd, n, first, total)) : stl_payload(fd, tris, n, first);
     if (ok && end) ok = ftruncate(fd, size) == 0 && pwrite_all(fd, (const unsigned char*)header, (size_t)hl, 0);
     if (!ok && ftruncate(fd, 0) != 0) ok = false;  // nothing that could pass for a finished file stays behind
     return close(fd) == 0 && ok ? 0 : DCSG_ERR_IO;
 }
 
-// One output file of a streamed export (stream_triangles_to_files), held open over all its pieces: BEGIN, the
-// reservation and the mapping of this writer's byte ranges happen once, each piece is then formatted straight into the
-// mapping, END comes with close().  Calling write_range per piece instead re-opened, re-reserved and re-mapped the
-// file every time, which on a 235 MB .ply cost more than a millisecond per piece (flat256 1024^3: .ply 12.8 -> 20.1 ms
-// in six pieces).  Same bytes, same crash-safety protocol as write_range.
+// One output file of a streamed export (stream_triangles_to_files), held open over all its pieces: BEGIN and the
+// reservation happen once, each piece is formatted into small buffers and pwritten at its final offsets, END comes with
+// close().  Calling write_range per piece instead re-opened and re-reserved the file every time, which on a 235 MB .ply
+// cost more than a millisecond per piece (flat256 1024^3: .ply 12.8 -> 20.1 ms in six pieces).  Same bytes, same
+// crash-safety protocol as write_range.
 class FileSink {
 public:
     // triangles [first, first + n) of a file of `total` will be written through this sink
@@ -2079,80 +1999,28 @@ public:
         if (fd_ < 0) return DCSG_ERR_IO;
         if (begin) {
             ok_ = pwrite_all(fd_, (const unsigned char*)kIncomplete, sizeof(kIncomplete) - 1, 0);
-            reserved_ = reserve_file(fd_, size_);
-        } else if (n) {
-            struct stat st;
-            reserved_ = fstat(fd_, &st) == 0 && st.st_size >= size_ && reserve_file(fd_, size_);
-        }
-        if (ok_ && n) {
-            if (ply) {
-                a_ = map_range(fd_, (off_t)hl_ + (off_t)(first * 72), (size_t)n * 72, reserved_);
-                b_ = map_range(fd_, (off_t)hl_ + (off_t)(total * 72) + (off_t)(first * 13), (size_t)n * 13, reserved_);
-                if (!a_.base || !b_.base) unmap(a_), unmap(b_);
-            } else {
-                a_ = map_range(fd_, (off_t)(84 + first * 50), (size_t)n * 50, reserved_);
-            }
+            reserve_file(fd_, size_);
         }
         return 0;
     }
-    // PLY: the face records of all n triangles of this sink -- (3; 3t, 3t+1, 3t+2) depends on nothing but t, so they can be
+    // PLY: the face records of all n triangles of this sink -- (3; 3t, 3t+1, 3t+2) depends on nothing but t, so they are
     // written while the first piece of vertices is still being projected / downloaded (15 % of the file's bytes)
     void write_faces_ahead(uint64_t n)
     {
-        if (!ok_ || !ply_ || !b_.base || !n || faces_done_) return;
-        unsigned char* fb = b_.base;
-        const uint64_t id0 = first_;
-        parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
-            unsigned char* q = fb + t0 * 13;
-            for (uint64_t t = id0 + t0; t < id0 + t1; t++, q += 13) {
-                q[0] = 3;
-                uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
-                memcpy(q + 1, idx, 12);
-            }
-            return true;
-        });
+        if (!ok_ || !ply_ || !n || faces_done_) return;
+        ok_ = ply_faces(fd_, n, first_, total_);
         faces_done_ = true;
     }
     // the piece `tris` = triangles [first + at, first + at + cnt)
     void write(const float* tris, uint64_t at, uint64_t cnt)
     {
         if (!ok_ || !cnt) return;
-        if (!a_.base) {  // no mapping: the buffered pwrite path of the range writers
-            ok_ = ply_ ? ply_payload(fd_, tris, cnt, first_ + at, total_, false) : stl_payload(fd_, tris, cnt, first_ + at, false);
-            return;
-        }
-        if (ply_) {
-            unsigned char *vb = a_.base + at * 72, *fb = b_.base + at * 13;
-            const uint64_t id0 = first_ + at;
-            const bool faces = !faces_done_;
-            parallel_ranges(cnt, writer_threads(), [=](uint64_t t0, uint64_t t1) {
-                unsigned char* o = vb + t0 * 72;
-                for (uint64_t i = t0 * 9; i < t1 * 9; i++, o += 8) {
-                    double v = (double)tris[i];
-                    memcpy(o, &v, 8);
-                }
-                if (!faces) return true;
-                unsigned char* q = fb + t0 * 13;
-                for (uint64_t t = id0 + t0; t < id0 + t1; t++, q += 13) {
-                    q[0] = 3;
-                    uint32_t idx[3] = {(uint32_t)(3 * t), (uint32_t)(3 * t + 1), (uint32_t)(3 * t + 2)};
-                    memcpy(q + 1, idx, 12);
-                }
-                return true;
-            });
-        } else {
-            unsigned char* base = a_.base + at * 50;
-            parallel_ranges(cnt, writer_threads(), [=](uint64_t t0, uint64_t t1) {
-                for (uint64_t t = t0; t < t1; t++) stl_record(base + t * 50, tris + t * 9);
-                return true;
-            });
-        }
+        if (ply_) ok_ = ply_vertices(fd_, tris, cnt, first_ + at, total_) && (faces_done_ || ply_faces(fd_, cnt, first_ + at, total_));
+        else ok_ = stl_payload(fd_, tris, cnt, first_ + at);
     }
     int close(bool end)
     {
         if (fd_ < 0) return DCSG_ERR_IO;
-        unmap(a_);
-        unmap(b_);
         if (ok_ && end) ok_ = ftruncate(fd_, size_) == 0 && pwrite_all(fd_, (const unsigned char*)header_, (size_t)hl_, 0);
         if (!ok_ && ftruncate(fd_, 0) != 0) ok_ = false;
         const bool closed = ::close(fd_) == 0;
@@ -2169,11 +2037,10 @@ public:
 
 private:
     int fd_ = -1, hl_ = 84;
-    bool ply_ = false, ok_ = true, reserved_ = false, faces_done_ = false;
+    bool ply_ = false, ok_ = true, faces_done_ = false;
     uint64_t first_ = 0, total_ = 0;
     off_t size_ = 0;
     char header_[512];
-    Mapping a_, b_;  // STL: records; PLY: vertices, faces
 };
 
 }  // namespace
