@@ -1215,7 +1215,23 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
         CL.cells = c->d_cells.p;
         CL.entries = (const unsigned*)c->d_cell_entries.p;
     }
+    // Levels below the minimum level emit no triangle and subdivide every node they keep, and they are small: they run back to
+    // back without the host learning their node counts -- the next level is launched for eight nodes per node (an upper
+    // bound) and reads its real count from where the scan left it (totals slot level & 1).  The count is read back where it
+    // is needed: at the sweep level, or when the bound grows past 2^21 nodes.  (Eight levels cost a 1024^3 export 0.4 ms of
+    // round trips before; a rank of a sharded export pays them in full.)
+    bool deferred = false;
+    const int sync_level = cfg->min_level > 2 ? cfg->min_level : 2;
     for (int level = 2; level <= cfg->max_level && n_nodes > 0; level++) {
+        if (deferred && (level >= sync_level || n_nodes > (1u << 21) || getenv("DCSG_MESH_SYNC_LEVELS"))) {
+            unsigned* totals = (unsigned*)c->h_words;
+            HIPCHK(c, hipMemcpyAsync(totals, d_totals + 2 * ((level - 1) & 1), 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            n_nodes = totals[0];
+            deferred = false;
+            if (!n_nodes) break;
+        }
+        const unsigned* n_nodes_dev = deferred ? d_totals + 2 * ((level - 1) & 1) : nullptr;
         P.level = level;
         for (int k = 0; k < 3; k++) P.hd[k] = hd[k];
         if (ns && level == ns->level) {
@@ -1280,7 +1296,7 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             HIPCHK(c, hipMemsetAsync(d_pending, 0, sizeof(unsigned), s));
             const size_t lds = c->scene.lds_bytes();
             void* args[] = {(void*)&blob, &nv, &P, (void*)&d_nodes, &n_nodes, (void*)&d_sdf, (void*)&d_normals,
-                            (void*)&d_table, (void*)&d_info, (void*)&d_bs, (void*)&d_bstats, (void*)&d_pending, &CL};
+                            (void*)&d_table, (void*)&d_info, (void*)&d_bs, (void*)&d_bstats, (void*)&d_pending, &CL, (void*)&n_nodes_dev};
             if ((r = launch(c, c->k->classify, n_blocks, DCSG_BLOCK, lds, s, args))) return r;
             if (level >= cfg->min_level && level != cfg->max_level) {  // the levels whose nodes can reach that test
                 // a wave per eight pending nodes; their number stays on the device: as many waves as could be needed, at
@@ -1291,14 +1307,21 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
                 if ((r = launch(c, c->k->complex_edges, blocks, DCSG_BLOCK, lds, s, cargs))) return r;
             }
         }
+        unsigned* d_level_totals = d_totals + 2 * (level & 1);
         {
-            void* args[] = {(void*)&d_bs, &n_blocks, (void*)&d_totals, (void*)&d_bstats, (void*)&d_ls};
+            void* args[] = {(void*)&d_bs, &n_blocks, (void*)&d_level_totals, (void*)&d_bstats, (void*)&d_ls};
             if ((r = launch(c, c->k->scan, 1, 1024, 0, s, args))) return r;
         }
-        unsigned* totals = (unsigned*)c->h_words;
-        HIPCHK(c, hipMemcpyAsync(totals, d_totals, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        unsigned n_children = totals[0], n_new_tris = totals[1];
+        unsigned n_children, n_new_tris = 0;
+        const bool defer = level < sync_level && level < cfg->max_level && (uint64_t)n_nodes * 8 <= (1u << 24);
+        if (defer) {
+            n_children = n_nodes * 8u;  // an upper bound; no triangles below the minimum level
+        } else {
+            unsigned* totals = (unsigned*)c->h_words;
+            HIPCHK(c, hipMemcpyAsync(totals, d_level_totals, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            n_children = totals[0], n_new_tris = totals[1];
+        }
         if ((r = ensure(c, c->d_nodes[cur ^ 1], (size_t)(n_children ? n_children : 1) * 3 * sizeof(float)))) return r;
         if ((r = ensure(c, c->d_tris, (size_t)(n_tris + n_new_tris + 1) * 9 * sizeof(float), true,
                         (size_t)n_tris * 9 * sizeof(float))))
@@ -1308,12 +1331,13 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             float* d_tris = (float*)c->d_tris.p;
             unsigned long long base = n_tris;
             void* args[] = {&P, (void*)&d_nodes, &n_nodes, (void*)&d_info, (void*)&d_bs, (void*)&d_table,
-                            (void*)&d_next, (void*)&d_tris, &base};
+                            (void*)&d_next, (void*)&d_tris, &base, (void*)&n_nodes_dev};
             if ((r = launch(c, c->k->emit, n_blocks, DCSG_BLOCK, 0, s, args))) return r;
         }
         st.triangles[level] = n_new_tris;
         n_tris += n_new_tris;
         n_nodes = n_children;
+        deferred = defer;
         cur ^= 1;
         for (int k = 0; k < 3; k++) hd[k] = 0.5f * hd[k];
     }

@@ -2034,8 +2034,11 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
                    unsigned int n_nodes, const float* __restrict__ sdf, const float* __restrict__ nrm,
                    const unsigned char* __restrict__ tri_table, unsigned short* __restrict__ info,
                    unsigned int* __restrict__ block_sums, unsigned int* __restrict__ block_stats,
-                   unsigned int* __restrict__ pending, DcsgCellLists CL)
+                   unsigned int* __restrict__ pending, DcsgCellLists CL, const unsigned int* __restrict__ n_nodes_dev)
 {
+    // the first levels run without a host round trip: n_nodes is then an upper bound (eight per node of the level before)
+    // and the level's real node count is what the previous level's scan left on the device
+    if (n_nodes_dev) n_nodes = *n_nodes_dev < n_nodes ? *n_nodes_dev : n_nodes;
     SceneLds scene = dcsg_stage_scene(blob, n_vec4);
     Sampler S = {&P, sdf, nrm, &scene, {1, 1, 1}, {0, 0, 0}};
     unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x;
@@ -2316,8 +2319,9 @@ extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
 dcsg_mesh_emit(DcsgMeshParams P, const float* __restrict__ nodes, unsigned int n_nodes,
                const unsigned short* __restrict__ info, const unsigned int* __restrict__ block_base,
                const unsigned char* __restrict__ tri_table, float* __restrict__ next_nodes,
-               float* __restrict__ tris, unsigned long long tri_base)
+               float* __restrict__ tris, unsigned long long tri_base, const unsigned int* __restrict__ n_nodes_dev)
 {
+    if (n_nodes_dev) n_nodes = *n_nodes_dev < n_nodes ? *n_nodes_dev : n_nodes;  // as in dcsg_mesh_classify
     __shared__ unsigned char table[256 * 16];  // per case: count, then up to 5 x 3 edge ids
     for (int k = threadIdx.x; k < 256 * 16 / 4; k += DCSG_BLOCK)
         reinterpret_cast<unsigned int*>(table)[k] = reinterpret_cast<const unsigned int*>(tri_table)[k];
