@@ -134,6 +134,16 @@ struct dcsg_ctx {
     unsigned char* h_ring = nullptr;
     size_t ring_slot_bytes = 0;
     hipEvent_t ring_ev[kRingSlots] = {};
+    // Pinning the ring's 64 MiB takes 10-12 ms (0.18 ms per MiB on the pool's boxes): a host thread started by dcsg_create
+    // does it while the context is built and the scene loads, instead of the first export (Design2 1024^3, scene files ->
+    // output files in a fresh process: 21 -> 12 ms).  The thread owns `job` until it is joined (take_ring).
+    struct RingJob {
+        std::thread th;
+        int device = 0;
+        unsigned char* p = nullptr;
+        size_t slot_bytes = 0;
+    };
+    std::unique_ptr<RingJob> ring_job;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t sweep_ev[8][2] = {};  // timing events of the dense sweeps, used in turn (sweep_device)
     int sweep_ev_next = 0;
@@ -653,6 +663,18 @@ int dcsg_create(dcsg_ctx** out, int device_id)
         CK(hipEventCreateWithFlags(&c->chunk_ready[k], hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&c->chunk_done[k], hipEventDisableTiming));
     }
+    if (!getenv("DCSG_NO_RING_PREALLOC")) {
+        c->ring_job.reset(new dcsg_ctx::RingJob);
+        dcsg_ctx::RingJob* job = c->ring_job.get();
+        job->device = device_id;
+        job->slot_bytes = dcsg_ctx::kRingSlotBytes;
+        job->th = std::thread([job] {
+            void* p = nullptr;
+            if (hipSetDevice(job->device) == hipSuccess &&
+                hipHostMalloc(&p, dcsg_ctx::kRingSlots * job->slot_bytes, hipHostMallocDefault) == hipSuccess)
+                job->p = (unsigned char*)p;
+        });
+    }
     std::string dir = library_dir(), bytes;
     if (!read_file(dir + "/dcsg_builtin.hsaco", bytes)) {
         c->err = "cannot read " + dir + "/dcsg_builtin.hsaco (run __graft_entry__.build())";
@@ -702,6 +724,11 @@ void dcsg_destroy(dcsg_ctx* c)
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_words) hipHostFree(c->h_words);
+    if (c->ring_job) {
+        if (c->ring_job->th.joinable()) c->ring_job->th.join();
+        if (c->ring_job->p) hipHostFree(c->ring_job->p);
+        c->ring_job.reset();
+    }
     if (c->h_ring) hipHostFree(c->h_ring);
     for (auto& e : c->ring_ev)
         if (e) hipEventDestroy(e);
@@ -2561,10 +2588,21 @@ int stream_triangles_to_files(dcsg_ctx* c, const char* stl_path, const char* ply
     dt_stl = dt_ply = t_last = 0;
     if (!n_writers) return 0;
     HIPCHK(c, hipSetDevice(c->device));
-    {   // the ring: four slots of a quarter of the mesh each, between 1 and 16 MiB (a small mesh does not pay for pinning
-        // 64 MiB); grown when a larger mesh comes
-        size_t want = (((size_t)T * 9 * sizeof(float) / dcsg_ctx::kRingSlots) + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
-        want = want > dcsg_ctx::kRingSlotBytes ? dcsg_ctx::kRingSlotBytes : want;
+    if (c->ring_job) {  // what dcsg_create's thread pinned in the meantime
+        if (c->ring_job->th.joinable()) c->ring_job->th.join();
+        if (c->ring_job->p && !c->h_ring) {
+            c->h_ring = c->ring_job->p;
+            c->ring_slot_bytes = c->ring_job->slot_bytes;
+        } else if (c->ring_job->p) {
+            hipHostFree(c->ring_job->p);
+        }
+        c->ring_job.reset();
+    }
+    // a piece: a quarter of the mesh, between 1 and 16 MiB; the ring: four slots that hold a piece each (without the
+    // pre-allocation a small mesh does not pay for pinning 64 MiB), grown when a larger mesh comes
+    size_t want = (((size_t)T * 9 * sizeof(float) / dcsg_ctx::kRingSlots) + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+    want = want > dcsg_ctx::kRingSlotBytes ? dcsg_ctx::kRingSlotBytes : want;
+    {
         if (!c->h_ring || want > c->ring_slot_bytes) {
             HIPCHK(c, hipStreamSynchronize(c->copy_stream));
             if (c->h_ring) HIPCHK(c, hipHostFree(c->h_ring));
@@ -2577,7 +2615,7 @@ int stream_triangles_to_files(dcsg_ctx* c, const char* stl_path, const char* ply
     }
     const int S = dcsg_ctx::kRingSlots;
     const size_t slot_bytes = c->ring_slot_bytes;
-    const uint64_t P = (slot_bytes / (9 * sizeof(float))) & ~(uint64_t)255;  // triangles per piece
+    const uint64_t P = (want / (9 * sizeof(float))) & ~(uint64_t)255;  // triangles per piece (want <= slot_bytes)
     // pieces never straddle the chunks of a pipelined projection (a piece is downloaded when ITS chunk is ready)
     struct Piece {
         uint64_t t, n;
