@@ -1901,7 +1901,6 @@ __device__ __forceinline__ int dcsg_edge_b(int e)
 struct Sampler {
     const DcsgMeshParams* P;
     const float* sdf;
-    const float* nrm;
     const SceneLds* scene;
     // Node-wise lattice, node below the sweep level: the lattice indices of its ancestor on that level, lo[k] .. hi[k].  The
     // ancestor was subdivided, so the sweep did not cull it (same rule on the same value, dcsg_node_culled) and wrote every
@@ -2040,7 +2039,7 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
     // and the level's real node count is what the previous level's scan left on the device
     if (n_nodes_dev) n_nodes = *n_nodes_dev < n_nodes ? *n_nodes_dev : n_nodes;
     SceneLds scene = dcsg_stage_scene(blob, n_vec4);
-    Sampler S = {&P, sdf, nrm, &scene, {1, 1, 1}, {0, 0, 0}};
+    Sampler S = {&P, sdf, &scene, {1, 1, 1}, {0, 0, 0}};
     unsigned int i = blockIdx.x * DCSG_BLOCK + threadIdx.x;
     unsigned int code = NODE_SKIP, lookup = 0, n_tri = 0;
     bool owned = false, culled = false, intersects = false, pend = false;

@@ -559,6 +559,41 @@ def test_projection_without_lattice(ev, oracle):
     assert np.array_equal(bits(t.cpu().numpy()), bits(want.reshape(-1, 3)))
 
 
+@pytest.mark.parametrize("name", ["design2", "flat256", "smooth256"])
+def test_export_switches_change_nothing(ev, name, monkeypatch, tmp_path):
+    """The round-4 restructurings of the export keep a switch each for measurements.  Every one of them must leave the mesh,
+    the level statistics, stage A and the files exactly as they are: the first levels of the mesher with a host round trip
+    each (DCSG_MESH_SYNC_LEVELS), every sample asking the node mask (DCSG_MESH_MASK_ALWAYS), on-demand samples through the
+    whole program instead of the cell lists (DCSG_MESH_NO_CELLS), a list per node instead of per eight siblings
+    (DCSG_NODE_GROUP_1), a block per node (DCSG_NODE_BLOCKS_PER_CU=0), other grids of stage A (its result is kept in
+    16 copies), normals swept densely, no export pipeline."""
+    cfg_txt = export_config_text(name, levels=(4, 6, 7), gd=3)
+
+    def run(env, dense=False):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        load(ev, name)
+        stl, ply = tmp_path / "a.stl", tmp_path / "a.ply"
+        st = ev.export(cfg_txt, str(stl), str(ply), dense_normals=dense)
+        out = (sorted_tris(ev.download_triangles()), [int(v) for v in st.mesh.nodes] + [int(v) for v in st.mesh.culled] +
+               [int(v) for v in st.mesh.leaves] + [int(v) for v in st.mesh.triangles], tuple(st.box_center), st.box_diameter, st.interior_points,
+               stl.read_bytes(), ply.read_bytes())
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    want = run({})
+    assert len(want[0]) > 1000
+    for env in ({"DCSG_MESH_SYNC_LEVELS": "1"}, {"DCSG_MESH_MASK_ALWAYS": "1"}, {"DCSG_MESH_NO_CELLS": "1"}, {"DCSG_NODE_GROUP_1": "1"},
+                {"DCSG_NODE_BLOCKS_PER_CU": "0"}, {"DCSG_BBOX_BLOCKS_PER_CU": "3"}, {"DCSG_BBOX_BLOCKS_PER_CU": "32"}, {"DCSG_NO_PIPELINE": "1"}):
+        got = run(env)
+        assert np.array_equal(got[0], want[0]), env
+        assert got[1:5] == want[1:5], env
+        assert got[5] == want[5] and got[6] == want[6], env
+    got = run({}, dense=True)
+    assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+
+
 @pytest.mark.parametrize("name", ["flat256", "grouped256", "smooth256", "mixed_groups"])
 def test_cell_list_projection(ev, oracle, name, monkeypatch):
     """Many-object scenes project through the cell lists (kernels.hip "Cell lists": a list of steps per cell of a cube
