@@ -1564,7 +1564,8 @@ int project_cells(dcsg_ctx* c, float* d_xyz, unsigned n, int steps, hipStream_t 
     unsigned blocks = (unsigned)c->n_cu * (unsigned)(per_cu < 1 ? 1 : per_cu);
     const unsigned groups = (n + DCSG_BLOCK - 1) / DCSG_BLOCK;
     if (blocks > groups) blocks = groups;
-    return launch(c, c->kb.project_cells, blocks, DCSG_BLOCK, c->scene.lds_bytes(), s, args);
+    // the kernel reads the scene's tables from LDS and nothing else of the scene's area (no interpreter stack, no list area)
+    return launch(c, c->kb.project_cells, blocks, DCSG_BLOCK, (size_t)nv * 16, s, args);
 }
 }  // namespace
 
