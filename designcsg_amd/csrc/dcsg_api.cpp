@@ -42,6 +42,7 @@ struct DevBuf {
 // module only: needs the known Lipschitz bounds of the built-in brushes; eval_points[4] aliases [1]).
 struct Kernels {
     hipFunction_t sweep[5] = {}, eval_points[5] = {}, bbox[5] = {}, project[5] = {};
+    hipFunction_t project_points = nullptr;  // per-scene code: a lane per stencil point (kernels.hip, dcsg_project_points_body)
     hipFunction_t classify = nullptr, complex_edges = nullptr, scan = nullptr, emit = nullptr, set_ad = nullptr, test_sqrt = nullptr, test_normal = nullptr;
     hipFunction_t set_ad_rest = nullptr;  // the rest part of a scene module has its own `arbitrary_data` pointer
     hipFunction_t sweep_d[5] = {}, sweep_f[5] = {};  // sweep[v] with the outputs fixed at compile time: SDF only / SDF + normals
@@ -241,6 +242,7 @@ int load_kernels(dcsg_ctx* c, hipModule_t mod, Kernels& k, int kind, int part = 
                    {"dcsg_project", &k.project[v], true}, {"dcsg_sweep_nodes", &k.sweep_nodes[v], true}};
         for (auto& t : tab)
             if (t.in_export ? exp : rest) HIPCHK(c, hipModuleGetFunction(t.f, mod, (std::string(t.name) + suffix[v]).c_str()));
+        if (v == 3 && exp) HIPCHK(c, hipModuleGetFunction(&k.project_points, mod, "dcsg_project_sp_points"));
         if (rest) {
             HIPCHK(c, hipModuleGetFunction(&k.sweep_d[v], mod, (std::string("dcsg_sweep") + suffix[v] + "_d").c_str()));
             HIPCHK(c, hipModuleGetFunction(&k.sweep_f[v], mod, (std::string("dcsg_sweep") + suffix[v] + "_f").c_str()));
@@ -1620,6 +1622,13 @@ int dcsg_project_vertices_device(dcsg_ctx* c, float* d_xyz, size_t n_vertices, i
     unsigned n = (unsigned)n_vertices;
     unsigned tiles = (n + DCSG_BLOCK - 1) / DCSG_BLOCK;
     void* args[] = {(void*)&blob, &nv, (void*)&d_xyz, &n, &steps};
+    if (c->variant == 3 && c->k->project_points && !c->light_scene && !getenv("DCSG_PROJECT_VERTEX_PER_LANE")) {
+        // per-scene code: eight vertices per wave, a lane per stencil point (32 vertices per block).  Kernel time of an
+        // export's projection, vertex per lane -> this: Design2 512^3 2.33 -> 1.10 ms, 1024^3 4.40 -> 2.80; not for scenes of
+        // a few standard brushes, whose evaluation is too small to be worth seven lanes (sphere 512^3 0.28 -> 0.46)
+        tiles = (n + DCSG_BLOCK / 8 - 1) / (DCSG_BLOCK / 8);
+        return launch(c, c->k->project_points, sweep_grid(c, tiles), DCSG_BLOCK, 0, (hipStream_t)stream, args);
+    }
     return launch(c, c->k->project[c->variant], sweep_grid(c, tiles), DCSG_BLOCK, c->scene.lds_bytes(), (hipStream_t)stream, args);
 }
 

@@ -2450,6 +2450,60 @@ __device__ __forceinline__ void dcsg_project_body(const uint4* __restrict__ blob
     }
 }
 
+#ifdef DCSG_HAVE_SPEC
+// The projection of per-scene code with a LANE PER STENCIL POINT: a wave holds eight vertices, lane 8 v + j the j-th point of
+// vertex v's stencil (0: the vertex, 1 .. 6: +x, -x, +y, -y, +z, -z as get_normal forms them, k2.cl:167-173; 7 idles on a
+// copy of the vertex).  One single-point evaluation per lane and step instead of a seven-point one, the seven values
+// exchanged within the group: a step costs a wave a seventh of the instructions, and fifty DEPENDENT steps are what a
+// projection launch is made of -- with a vertex per lane a launch over a quarter of Design2's 512^3 vertices (0.8 waves per
+// SIMD) took 0.6 ms whatever its size.  Every lane of a group computes the same normal and the same update from the same
+// seven values, so the group's lanes stay identical copies of the vertex's state; a wave ends when its eight vertices have
+// retired (the slowest of 8, not of 64).  Same points, same arithmetic as dcsg_stencil_spec: same bits.
+__device__ __forceinline__ void dcsg_project_points_body(float* __restrict__ verts, unsigned int n_verts, int steps)
+{
+    const unsigned int lane = threadIdx.x & (DCSG_WAVE - 1u), j = lane & 7u, group0 = lane & ~7u;
+    const unsigned int per_block = DCSG_BLOCK / 8u;
+    const unsigned int tiles = (n_verts + per_block - 1u) / per_block;
+    const float e = (float)K2_NORMAL_EPSILON, zero = 0.0f;
+    for (unsigned int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const unsigned int i = tile * per_block + threadIdx.x / 8u;
+        const bool live = i < n_verts;
+        const unsigned int ci = live ? i : n_verts - 1u;
+        DcsgDescent d = {verts[(size_t)ci * 3 + 0], verts[(size_t)ci * 3 + 1], verts[(size_t)ci * 3 + 2], 0.0f, 0.0f, 0.0f, false, !live};
+        for (int k = 0; k < steps; k++) {
+            if (__builtin_amdgcn_ballot_w64(!d.done) == 0ull) break;
+            const float x = d.x, y = d.y, z = d.z;
+            // the lane's point: v + dx adds +0.0 on the other axes, v - dx subtracts it
+            const bool minus = j == 2u || j == 4u || j == 6u;
+            const float sx = (j == 1u || j == 2u) ? e : zero, sy = (j == 3u || j == 4u) ? e : zero, sz = (j == 5u || j == 6u) ? e : zero;
+            const bool centre = j == 0u || j == 7u;
+            const float qx = centre ? x : (minus ? x - sx : x + sx), qy = centre ? y : (minus ? y - sy : y + sy),
+                        qz = centre ? z : (minus ? z - sz : z + sz);
+            float f, u0, u1, u2;
+            dcsg_stencil_spec<false>(qx, qy, qz, true, false, f, u0, u1, u2);
+            const float sd = __shfl(f, (int)group0, DCSG_WAVE);
+            const float Dx = __shfl(f, (int)group0 + 1, DCSG_WAVE) - __shfl(f, (int)group0 + 2, DCSG_WAVE);
+            const float Dy = __shfl(f, (int)group0 + 3, DCSG_WAVE) - __shfl(f, (int)group0 + 4, DCSG_WAVE);
+            const float Dz = __shfl(f, (int)group0 + 5, DCSG_WAVE) - __shfl(f, (int)group0 + 6, DCSG_WAVE);
+            float nx, ny, nz;
+            dcsg_finish_normal(Dx, Dy, Dz, nx, ny, nz);
+            const float m = -sd;  // v3f_scale(n, -s) then v3f_add, CVector.cpp:128-149
+            dcsg_descent_advance(d, x + m * nx, y + m * ny, z + m * nz, k, steps);
+        }
+        if (live && j == 0u) {
+            verts[(size_t)i * 3 + 0] = d.x;
+            verts[(size_t)i * 3 + 1] = d.y;
+            verts[(size_t)i * 3 + 2] = d.z;
+        }
+    }
+}
+extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)
+dcsg_project_sp_points(const uint4* __restrict__ /*blob*/, int /*n_vec4*/, float* __restrict__ verts, unsigned int n_verts, int steps)
+{
+    dcsg_project_points_body(verts, n_verts, steps);
+}
+#endif
+
 #define DCSG_PROJECT_KERNEL(NAME, K)                                                                                \
     extern "C" __global__ void __launch_bounds__(DCSG_BLOCK)                                                        \
     NAME(const uint4* __restrict__ blob, int n_vec4, float* __restrict__ verts, unsigned int n_verts, int steps)    \
