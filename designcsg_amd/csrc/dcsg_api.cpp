@@ -112,7 +112,9 @@ struct dcsg_ctx {
     DevBuf d_blob, d_ad, d_tri_table, d_pts, d_out, d_nodes[2], d_info, d_block_sums, d_small, d_tris, d_lat_sdf,
         d_lat_nrm, d_dd_table, d_dd_rep, d_dd_slot, d_dd_compact, d_rt_keep, d_rt_out;
     // cell lists (kernels.hip "Cell lists"): built on the first projection of a many-object scene, kept until the next scene
-    DevBuf d_pending, d_cells, d_cell_entries, d_cell_want, d_cell_words, d_cell_work;
+    int pattern_key = -1;      // the node sweep's point pattern in d_pattern: shift | step << 8 | edges << 24
+    unsigned n_pattern = 0;
+    DevBuf d_pending, d_pattern, d_cells, d_cell_entries, d_cell_want, d_cell_words, d_cell_work;
     DcsgCellGrid cell_grid = {};
     bool cells_valid = false;
     double cells_built_ms = 0;  // host-side time spent building cells of the loaded scene so far (launch to completion)
@@ -726,7 +728,7 @@ void dcsg_destroy(dcsg_ctx* c)
     DevBuf* bufs[] = {&c->d_blob,  &c->d_ad,         &c->d_tri_table, &c->d_pts,  &c->d_out,     &c->d_nodes[0],
                       &c->d_nodes[1], &c->d_info,    &c->d_block_sums, &c->d_small, &c->d_tris, &c->d_lat_sdf,
                       &c->d_lat_nrm, &c->d_dd_table, &c->d_dd_rep, &c->d_dd_slot, &c->d_dd_compact, &c->d_node_mask,
-                      &c->d_rt_keep, &c->d_rt_out, &c->d_pending, &c->d_cells, &c->d_cell_entries, &c->d_cell_want, &c->d_cell_words, &c->d_cell_work};
+                      &c->d_rt_keep, &c->d_rt_out, &c->d_pending, &c->d_pattern, &c->d_cells, &c->d_cell_entries, &c->d_cell_want, &c->d_cell_words, &c->d_cell_work};
     for (auto* b : bufs) release(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_words) hipHostFree(c->h_words);
@@ -1286,8 +1288,43 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             // blend radius widens every bound, and a box of eight coarse nodes keeps too much: those scenes group only
             // from level 7 on (nodes of 1/128 of the box).
             int group = (c->variant == 4 && n_nodes % 8 == 0 && (!c->scene.has_smooth || level >= 7) && !getenv("DCSG_NODE_GROUP_1")) ? 8 : 1;
+            // The points of a node that the mesher can read (kernels.hip, dcsg_in_sweep_pattern: corners and centres of nodes down
+            // to the maximum level, every point along the edges of the levels that make the edge-ambiguity test); the sweep
+            // writes those only.  7/9/10: 297 of a node's 729 points.  Nothing to leave out when the maximum level is the
+            // grid level (DCSG_SWEEP_ALL_POINTS: the whole node, as rounds 1-3 swept it).
+            const int step = 1 << (cfg->grid_level - cfg->max_level);
+            const bool edges = cfg->max_level > level;
+            unsigned n_pattern = 0;
+            const unsigned short* d_pattern = nullptr;
+            const int pattern_key = shift | step << 8 | (edges ? 1 << 24 : 0);
+            if (step > 1 && !getenv("DCSG_SWEEP_ALL_POINTS") && c->pattern_key == pattern_key) {  // the same export configuration as before
+                n_pattern = c->n_pattern;
+                d_pattern = (const unsigned short*)c->d_pattern.p;
+                P.pattern_step = step;
+                P.pattern_edges = edges ? 1 : 0;
+            } else if (step > 1 && !getenv("DCSG_SWEEP_ALL_POINTS")) {
+                std::vector<unsigned short> pat;
+                const int S = 1 << shift;
+                for (int lz = 0; lz <= S; lz++)
+                    for (int ly = 0; ly <= S; ly++)
+                        for (int lx = 0; lx <= S; lx++) {
+                            const int m = step - 1, h = step >> 1, e = 2 * step - 1;
+                            const bool corner = ((lx | ly | lz) & m) == 0, centre = (lx & m) == h && (ly & m) == h && (lz & m) == h;
+                            const bool on_edge = edges && ((lx & e) == 0) + ((ly & e) == 0) + ((lz & e) == 0) >= 2;
+                            if (corner || centre || on_edge) pat.push_back((unsigned short)(lx | ly << 5 | lz << 10));
+                        }
+                n_pattern = (unsigned)pat.size();
+                if ((r = ensure(c, c->d_pattern, pat.size() * sizeof(unsigned short)))) return r;
+                HIPCHK(c, hipMemcpyAsync(c->d_pattern.p, pat.data(), pat.size() * sizeof(unsigned short), hipMemcpyHostToDevice, s));
+                HIPCHK(c, hipStreamSynchronize(s));  // `pat` goes out of scope
+                d_pattern = (const unsigned short*)c->d_pattern.p;
+                P.pattern_step = step;
+                P.pattern_edges = edges ? 1 : 0;
+                c->pattern_key = pattern_key;
+                c->n_pattern = n_pattern;
+            }
             void* args[] = {(void*)&blob, &nv, &P.lat, (void*)&d_list, &n_nodes, &sh, &lvl, (void*)&ns->d_sdf, (void*)&ns->d_nrm,
-                            (void*)&d_mask, &P.hd[0], &P.hd[1], &P.hd[2], &zo_lo, &zo_hi, (void*)&d_swept, &group};
+                            (void*)&d_mask, &P.hd[0], &P.hd[1], &P.hd[2], &zo_lo, &zo_hi, (void*)&d_swept, &group, (void*)&d_pattern, &n_pattern};
             HIPCHK(c, hipEventRecord(c->ev0, s));
             // blocks walk the list with a stride: as many as keep the chip full several times over, each adding its count of
             // swept nodes once (DCSG_NODE_BLOCKS_PER_CU, 0 = a block per node or group as in rounds 1-3)
@@ -1304,7 +1341,7 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             ns->ms = ms;
             ns->nodes = swept;  // nodes of this slab that the cull rule kept
             const uint64_t side = ((uint64_t)1 << shift) + 1;
-            ns->points = (uint64_t)swept * side * side * side;
+            ns->points = (uint64_t)swept * (n_pattern ? (uint64_t)n_pattern : side * side * side);
             d_sdf = ns->d_sdf;
             d_normals = ns->d_nrm;
             P.z_lo = 0;

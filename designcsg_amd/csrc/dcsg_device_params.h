@@ -41,6 +41,7 @@ struct DcsgMeshParams {
     const unsigned char* node_mask;
     int mask_level, mask_shift;
     int use_spec;  // on-demand samples through the module's per-scene specialised code (spec kernel set only)
+    int pattern_step, pattern_edges;  // node-wise lattice: which points of a swept node were written (kernels.hip, dcsg_in_sweep_pattern); step 1 = all
     int mask_check;  // diagnostic (DCSG_MESH_MASK_ALWAYS): every sample asks the node mask, also inside its own swept node
 };
 

@@ -1533,21 +1533,30 @@ __device__ __forceinline__ bool dcsg_node_outside_slab(int i0z, int shift, int z
 
 // Local point index p of a node block -> (lx, ly, lz), p = (lz*side + ly)*side + lx, without integer division:
 // side = 2^shift + 1 <= 33 and p < side^3 < 2^16, for which floor(p * (floor(2^32/d) + 1) / 2^32) = p / d exactly.
+// `pattern` (n_pattern > 0): the node's points that the mesher can read, as lx | ly << 5 | lz << 10 -- the sweep then writes
+// those and nothing else (dcsg_in_sweep_pattern has the rule; the host builds the list from the same rule).
 struct DcsgNodeGrid {
     unsigned int side, ss, pts, m_side, m_ss;
+    const unsigned short* pattern;
 };
-__device__ __forceinline__ DcsgNodeGrid dcsg_node_grid(int shift)
+__device__ __forceinline__ DcsgNodeGrid dcsg_node_grid(int shift, const unsigned short* pattern = nullptr, unsigned int n_pattern = 0u)
 {
     DcsgNodeGrid g;
     g.side = (1u << shift) + 1u;
     g.ss = g.side * g.side;
-    g.pts = g.ss * g.side;
+    g.pts = n_pattern ? n_pattern : g.ss * g.side;
     g.m_side = 0xffffffffu / g.side + 1u;
     g.m_ss = 0xffffffffu / g.ss + 1u;
+    g.pattern = n_pattern ? pattern : nullptr;
     return g;
 }
 __device__ __forceinline__ void dcsg_node_local(const DcsgNodeGrid& g, unsigned int p, unsigned int& lx, unsigned int& ly, unsigned int& lz)
 {
+    if (g.pattern) {  // kernel argument: uniform
+        const unsigned int v = g.pattern[p];
+        lx = v & 31u, ly = (v >> 5) & 31u, lz = v >> 10;
+        return;
+    }
     lz = __umulhi(p, g.m_ss);
     unsigned int r = p - lz * g.ss;
     ly = __umulhi(r, g.m_side);
@@ -1570,11 +1579,12 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
                                                       const float* __restrict__ nodes, unsigned int n_nodes, int shift, int level,
                                                       float* __restrict__ sdf_out, float* __restrict__ nrm_out,
                                                       unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz,
-                                                      int z_own_lo, int z_own_hi, unsigned int* __restrict__ n_swept)
+                                                      int z_own_lo, int z_own_hi, unsigned int* __restrict__ n_swept,
+                                                      const unsigned short* __restrict__ pattern, unsigned int n_pattern)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     __shared__ float tab[3 * DCSG_NODE_TAB];
-    const DcsgNodeGrid g = dcsg_node_grid(shift);
+    const DcsgNodeGrid g = dcsg_node_grid(shift, pattern, n_pattern);
     const size_t n1 = (size_t)L.res + 1u;
     unsigned int swept_here = 0u;  // block-uniform; one atomic per block at the end (one per node, all on the same word, retire one at a time)
     for (unsigned int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
@@ -1652,10 +1662,11 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,                 \
          unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,       \
          unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz, int z_own_lo, int z_own_hi,        \
-         unsigned int* __restrict__ n_swept)                                                                         \
+         unsigned int* __restrict__ n_swept, int /*group: the culling kernel's*/,                                   \
+         const unsigned short* __restrict__ pattern, unsigned int n_pattern)                                         \
     {                                                                                                                \
         dcsg_sweep_nodes_body<K>(blob, n_vec4, L, nodes, n_nodes, shift, level, sdf_out, nrm_out, node_mask, hdx,    \
-                                 hdy, hdz, z_own_lo, z_own_hi, n_swept);                                             \
+                                 hdy, hdz, z_own_lo, z_own_hi, n_swept, pattern, n_pattern);                         \
     }
 #ifdef DCSG_PART_EXPORT
 #ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
@@ -1912,6 +1923,26 @@ __device__ __forceinline__ bool dcsg_sample_in_swept_node(const Sampler& S, int 
 {
     return ix >= S.lo[0] && ix <= S.hi[0] && iy >= S.lo[1] && iy <= S.hi[1] && iz >= S.lo[2] && iz <= S.hi[2];
 }
+// Node-wise lattice: which points of a swept node the sweep wrote.  The mesher reads, inside a node of the sweep level,
+// (A) corners and centres of nodes down to the maximum level -- with s = 2^(gridLevel - maximumOctreeLevel) lattice steps per
+// such node: all three indices multiples of s, or all three congruent s/2 -- and (B) the edge-ambiguity samples of the levels
+// that make the test (minimum ... maximum - 1): every lattice point along an edge of such a node, i.e. at least two indices
+// multiples of 2 s.  Everything else in the node is never looked at (at 7/9/10: 297 of 729 points), and the sweep leaves it
+// out.  A sample outside the pattern -- possible only if float rounding moved it -- is evaluated on demand like any other
+// point the lattice does not hold.  P.pattern_step = s (1: every point), P.pattern_edges = rule (B) applies.
+__device__ __forceinline__ bool dcsg_in_sweep_pattern(const DcsgMeshParams& P, int ix, int iy, int iz)
+{
+    const int s = P.pattern_step;
+    if (s <= 1) return true;
+    const int m = s - 1, h = s >> 1, rx = ix & m, ry = iy & m, rz = iz & m;
+    if ((rx | ry | rz) == 0) return true;
+    if (rx == h && ry == h && rz == h) return true;
+    if (P.pattern_edges) {
+        const int e = 2 * s - 1;
+        if (((ix & e) == 0 ? 1 : 0) + ((iy & e) == 0 ? 1 : 0) + ((iz & e) == 0 ? 1 : 0) >= 2) return true;
+    }
+    return false;
+}
 
 // Node-wise sweep: is lattice point (ix,iy,iz) inside a swept node?  A point on a node face belongs to two nodes per
 // axis, so up to eight mask bytes are looked at (one for a point strictly inside a node).
@@ -1942,7 +1973,8 @@ __device__ __forceinline__ float sample_sdf(const Sampler& S, const float p[3])
 {
     const DcsgLattice& L = S.P->lat;
     int ix = dcsg_snap(L, 0, p[0]), iy = dcsg_snap(L, 1, p[1]), iz = dcsg_snap(L, 2, p[2]);
-    if (iz >= S.P->z_lo && iz <= S.P->z_hi && (dcsg_sample_in_swept_node(S, ix, iy, iz) || dcsg_lattice_point_written(*S.P, ix, iy, iz))) {
+    if (iz >= S.P->z_lo && iz <= S.P->z_hi && dcsg_in_sweep_pattern(*S.P, ix, iy, iz) &&
+        (dcsg_sample_in_swept_node(S, ix, iy, iz) || dcsg_lattice_point_written(*S.P, ix, iy, iz))) {
         size_t n1 = (size_t)L.res + 1;
         return S.sdf[((size_t)(iz - S.P->z_lo) * n1 + iy) * n1 + ix];
     }
@@ -2070,7 +2102,8 @@ dcsg_mesh_classify(const uint4* __restrict__ blob, int n_vec4, DcsgMeshParams P,
         }
         // (at the sweep level itself the node may be one the sweep culled: its centre asks the mask)
         const bool in_swept = P.level > P.mask_level && dcsg_sample_in_swept_node(S, ix, iy, iz);
-        const bool held = intersects && iz >= P.z_lo && iz <= P.z_hi && (in_swept || dcsg_lattice_point_written(P, ix, iy, iz));
+        const bool held = intersects && iz >= P.z_lo && iz <= P.z_hi && dcsg_in_sweep_pattern(P, ix, iy, iz) &&
+                          (in_swept || dcsg_lattice_point_written(P, ix, iy, iz));
         if (held) {
             const size_t n1 = (size_t)L.res + 1;
             d = sdf[((size_t)(iz - P.z_lo) * n1 + iy) * n1 + ix];
@@ -2206,7 +2239,8 @@ dcsg_mesh_complex_edges(const uint4* __restrict__ blob, int n_vec4, DcsgMeshPara
         dcsg_corner(k, 1.0f, c, P.hd, p);
         // the normal AT THE SNAPPED corner (ISV3D64::getValue semantics, as for the SDF); read where the lattice holds normals
         const int ix = dcsg_snap(L, 0, p[0]), iy = dcsg_snap(L, 1, p[1]), iz = dcsg_snap(L, 2, p[2]);
-        const bool held = P.has_normals && iz >= P.z_lo && iz <= P.z_hi && dcsg_lattice_point_written(P, ix, iy, iz);
+        const bool held = P.has_normals && iz >= P.z_lo && iz <= P.z_hi && dcsg_in_sweep_pattern(P, ix, iy, iz) &&
+                          dcsg_lattice_point_written(P, ix, iy, iz);
         float nx, ny, nz;
         dcsg_point_normal(scene, CL, live && !held, dcsg_lattice_coord(L, 0, ix), dcsg_lattice_coord(L, 1, iy), dcsg_lattice_coord(L, 2, iz), nx,
                           ny, nz);
@@ -2792,11 +2826,12 @@ extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, DCSG_C4_WAVES)
 dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,
                     unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,
                     unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz, int z_own_lo, int z_own_hi,
-                    unsigned int* __restrict__ n_swept, int group)
+                    unsigned int* __restrict__ n_swept, int group, const unsigned short* __restrict__ pattern,
+                    unsigned int n_pattern)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
     __shared__ float tab[3 * DCSG_NODE_TAB];
-    const DcsgNodeGrid g = dcsg_node_grid(shift);
+    const DcsgNodeGrid g = dcsg_node_grid(shift, pattern, n_pattern);
     const unsigned int side = g.side, pts = g.pts;
     const size_t n1 = (size_t)L.res + 1u;
     const float pad = nrm_out ? (float)K2_NORMAL_EPSILON * 1.01f : 0.0f;

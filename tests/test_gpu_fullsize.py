@@ -82,7 +82,22 @@ def test_node_wise_sweep_equals_dense_sweep_at_512(ev, name, levels):
     assert b.swept_nodes == 0 and b.swept_points == b.lattice_points == 513 ** 3
     m = levels[0]
     side = (1 << (9 - m)) + 1
-    assert a.swept_nodes == 8 * a.mesh.subdivided[m - 1] - a.mesh.culled[m] and a.swept_points == a.swept_nodes * side ** 3
+    # of a swept node's side^3 points the sweep writes those the mesher can read (kernels.hip, dcsg_in_sweep_pattern): corners
+    # and centres of nodes down to the maximum level, every point along the edges of the levels that make the edge test
+    step, S = 1 << (9 - levels[1]), side - 1
+    edges = levels[1] > m
+    r = np.arange(side)
+    lz, ly, lx = np.meshgrid(r, r, r, indexing="ij")
+    if step > 1:
+        corner = ((lx | ly | lz) & (step - 1)) == 0
+        centre = ((lx & (step - 1)) == step // 2) & ((ly & (step - 1)) == step // 2) & ((lz & (step - 1)) == step // 2)
+        e = 2 * step - 1
+        on_edge = (((lx & e) == 0).astype(int) + ((ly & e) == 0) + ((lz & e) == 0) >= 2) & edges
+        per_node = int((corner | centre | on_edge).sum())
+        assert per_node < side ** 3
+    else:
+        per_node = side ** 3
+    assert a.swept_nodes == 8 * a.mesh.subdivided[m - 1] - a.mesh.culled[m] and a.swept_points == a.swept_nodes * per_node
     assert a.swept_points * 3 < b.swept_points
 
 

@@ -565,7 +565,8 @@ def test_export_switches_change_nothing(ev, name, monkeypatch, tmp_path):
     the level statistics, stage A and the files exactly as they are: the first levels of the mesher with a host round trip
     each (DCSG_MESH_SYNC_LEVELS), every sample asking the node mask (DCSG_MESH_MASK_ALWAYS), on-demand samples through the
     whole program instead of the cell lists (DCSG_MESH_NO_CELLS), a list per node instead of per eight siblings
-    (DCSG_NODE_GROUP_1), a block per node (DCSG_NODE_BLOCKS_PER_CU=0), other grids of stage A (its result is kept in
+    (DCSG_NODE_GROUP_1), a block per node (DCSG_NODE_BLOCKS_PER_CU=0), every point of a swept node instead of those the mesher
+    reads (DCSG_SWEEP_ALL_POINTS), a vertex per lane in the projection (DCSG_PROJECT_VERTEX_PER_LANE), other grids of stage A (its result is kept in
     16 copies), normals swept densely, no export pipeline."""
     cfg_txt = export_config_text(name, levels=(4, 6, 7), gd=3)
 
@@ -585,7 +586,7 @@ def test_export_switches_change_nothing(ev, name, monkeypatch, tmp_path):
     want = run({})
     assert len(want[0]) > 1000
     for env in ({"DCSG_MESH_SYNC_LEVELS": "1"}, {"DCSG_MESH_MASK_ALWAYS": "1"}, {"DCSG_MESH_NO_CELLS": "1"}, {"DCSG_NODE_GROUP_1": "1"},
-                {"DCSG_NODE_BLOCKS_PER_CU": "0"}, {"DCSG_BBOX_BLOCKS_PER_CU": "3"}, {"DCSG_BBOX_BLOCKS_PER_CU": "32"}, {"DCSG_NO_PIPELINE": "1"}):
+                {"DCSG_NODE_BLOCKS_PER_CU": "0"}, {"DCSG_SWEEP_ALL_POINTS": "1"}, {"DCSG_PROJECT_VERTEX_PER_LANE": "1"}, {"DCSG_BBOX_BLOCKS_PER_CU": "3"}, {"DCSG_BBOX_BLOCKS_PER_CU": "32"}, {"DCSG_NO_PIPELINE": "1"}):
         got = run(env)
         assert np.array_equal(got[0], want[0]), env
         assert got[1:5] == want[1:5], env
