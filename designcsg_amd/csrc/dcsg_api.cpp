@@ -1287,7 +1287,9 @@ int mesh_impl(dcsg_ctx* c, const float center[3], float diameter, const dcsg_exp
             // 0.4; grouped256 6.0 / 3.3, 1.6 / 1.3; smooth256 10.9 / 9.3 but 3.0 / 3.5 at 512^3 -- with smooth joins the
             // blend radius widens every bound, and a box of eight coarse nodes keeps too much: those scenes group only
             // from level 7 on (nodes of 1/128 of the box).
-            int group = (c->variant == 4 && n_nodes % 8 == 0 && (!c->scene.has_smooth || level >= 7) && !getenv("DCSG_NODE_GROUP_1")) ? 8 : 1;
+            // The other kernels take eight siblings per block iteration as well (no list to build: the points of the swept ones are
+            // walked as one range, kernels.hip dcsg_node_group).
+            int group = (n_nodes % 8 == 0 && (c->variant != 4 || !c->scene.has_smooth || level >= 7) && !getenv("DCSG_NODE_GROUP_1")) ? 8 : 1;
             // The points of a node that the mesher can read (kernels.hip, dcsg_in_sweep_pattern: corners and centres of nodes down
             // to the maximum level, every point along the edges of the levels that make the edge-ambiguity test); the sweep
             // writes those only.  7/9/10: 297 of a node's 729 points.  Nothing to leave out when the maximum level is the

@@ -1562,16 +1562,50 @@ __device__ __forceinline__ void dcsg_node_local(const DcsgNodeGrid& g, unsigned 
     ly = __umulhi(r, g.m_side);
     lx = r - ly * g.side;
 }
-// The node's 3 x side lattice coordinates (ISV.hpp:103-109) once per node into LDS; tab[k*40 + j] = axis k, index i0[k]+j.
-#define DCSG_NODE_TAB 40
-__device__ __forceinline__ void dcsg_node_axes(const DcsgLattice& L, const int (&i0)[3], unsigned int side, float* tab)
+// The nodes of a group (eight siblings, or one node) that are swept, and the flattened walk over their points.
+// Phase 1 -- every WAVE on its own, no barrier: lane l looks at node l & 7 of the group (origin, slab, the cull rule on the
+// value at its snapped centre; one evaluation serves the eight centres), the ballot's low eight bits are the nodes to sweep.
+// Phase 2: the block walks the kept nodes' points as ONE index range t = rank * pts + p (rank-th kept node, p-th point of
+// the node's pattern), 256 or 1 024 at a time, so that a node of 297 points does not leave half of a second pass idle; the
+// node's origin comes from the lane that looked at it (lane exchange), the coordinates from the lattice's own formula.
+struct DcsgNodeGroup {
+    unsigned int mask;      // bit k: node k of the group is swept (wave-uniform)
+    int ox, oy, oz;         // lane l: first lattice index of node l & 7
+};
+template <class CentreEval>
+__device__ __forceinline__ DcsgNodeGroup dcsg_node_group(const DcsgLattice& L, const float* __restrict__ nodes, unsigned int n_first,
+                                                         unsigned int n_end, int shift, int level, float hdx, float hdy, float hdz,
+                                                         int z_own_lo, int z_own_hi, unsigned char* __restrict__ node_mask, CentreEval eval)
 {
-    __syncthreads();  // the previous node's readers are done
-    if (threadIdx.x < 3u * DCSG_NODE_TAB) {
-        const unsigned int k = threadIdx.x / DCSG_NODE_TAB, j = threadIdx.x - k * DCSG_NODE_TAB;
-        if (j < side) tab[threadIdx.x] = dcsg_lattice_coord(L, (int)k, i0[k] + (int)j);
-    }
-    __syncthreads();
+    const unsigned int k = threadIdx.x & 7u;
+    const bool exists = n_first + k < n_end;
+    int i0[3], ic[3];
+    size_t slot;
+    dcsg_node_origin(L, nodes, exists ? n_first + k : n_first, shift, level, i0, ic, slot);
+    const bool inside = exists && !dcsg_node_outside_slab(i0[2], shift, z_own_lo, z_own_hi);
+    const float d = eval(dcsg_lattice_coord(L, 0, ic[0]), dcsg_lattice_coord(L, 1, ic[1]), dcsg_lattice_coord(L, 2, ic[2]));
+    const bool keep = inside && !dcsg_node_culled(d, hdx, hdy, hdz);
+    DcsgNodeGroup G;
+    G.mask = (unsigned int)(__builtin_amdgcn_ballot_w64(keep) & 0xffull);
+    G.ox = i0[0], G.oy = i0[1], G.oz = i0[2];
+    if (threadIdx.x < 8u && keep) node_mask[slot] = 1;  // lanes 0 .. 7 of the block's first wave
+    return G;
+}
+// point t of the walk (t < popcount(mask) * pts, clamped by the caller): its coordinates and its place in the lattice
+__device__ __forceinline__ void dcsg_node_group_point(const DcsgLattice& L, const DcsgNodeGrid& g, const DcsgNodeGroup& G, unsigned int m_pts,
+                                                      unsigned int t, float& x, float& y, float& z, size_t& at)
+{
+    const unsigned int rank = __umulhi(t, m_pts), p = t - rank * g.pts;  // t / pts, exact below 2^16
+    unsigned int c = G.mask;
+    for (unsigned int i = 0u; i < rank; i++) c &= c - 1u;
+    const int child = __builtin_ctz(c | 0x100u);
+    unsigned int lx, ly, lz;
+    dcsg_node_local(g, p, lx, ly, lz);
+    const int ix = __shfl(G.ox, child, DCSG_WAVE) + (int)lx, iy = __shfl(G.oy, child, DCSG_WAVE) + (int)ly,
+              iz = __shfl(G.oz, child, DCSG_WAVE) + (int)lz;
+    x = dcsg_lattice_coord(L, 0, ix), y = dcsg_lattice_coord(L, 1, iy), z = dcsg_lattice_coord(L, 2, iz);
+    const size_t n1 = (size_t)L.res + 1u;
+    at = ((size_t)iz * n1 + (size_t)iy) * n1 + (size_t)ix;
 }
 
 template <int K>
@@ -1579,60 +1613,56 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
                                                       const float* __restrict__ nodes, unsigned int n_nodes, int shift, int level,
                                                       float* __restrict__ sdf_out, float* __restrict__ nrm_out,
                                                       unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz,
-                                                      int z_own_lo, int z_own_hi, unsigned int* __restrict__ n_swept,
+                                                      int z_own_lo, int z_own_hi, unsigned int* __restrict__ n_swept, int group,
                                                       const unsigned short* __restrict__ pattern, unsigned int n_pattern)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
-    __shared__ float tab[3 * DCSG_NODE_TAB];
     const DcsgNodeGrid g = dcsg_node_grid(shift, pattern, n_pattern);
-    const size_t n1 = (size_t)L.res + 1u;
+    const unsigned int m_pts = 0xffffffffu / g.pts + 1u;
+    const unsigned int per = (unsigned int)group, n_groups = (n_nodes + per - 1u) / per;
     unsigned int swept_here = 0u;  // block-uniform; one atomic per block at the end (one per node, all on the same word, retire one at a time)
-    for (unsigned int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
-        int i0[3], ic[3];
-        size_t slot;
-        dcsg_node_origin(L, nodes, n, shift, level, i0, ic, slot);
-        if (dcsg_node_outside_slab(i0[2], shift, z_own_lo, z_own_hi)) continue;
-        {   // every lane evaluates the same point: uniform, no divergence
-            float cx = dcsg_lattice_coord(L, 0, ic[0]), cy = dcsg_lattice_coord(L, 1, ic[1]), cz = dcsg_lattice_coord(L, 2, ic[2]);
-            float d, u0, u1, u2;
-            if (K == 0) d = dcsg_primary_sdf(s, cx, cy, cz);
+    for (unsigned int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const unsigned int n_first = grp * per, n_end = n_first + per < n_nodes ? n_first + per : n_nodes;
+        const DcsgNodeGroup G = dcsg_node_group(L, nodes, n_first, n_end, shift, level, hdx, hdy, hdz, z_own_lo, z_own_hi, node_mask,
+                                                [&](float cx, float cy, float cz) {
+                                                    float d = 0.0f, u0, u1, u2;
+                                                    if (K == 0) d = dcsg_primary_sdf(s, cx, cy, cz);
 #ifdef DCSG_HAVE_SPEC
-            else if (K < 0) dcsg_stencil_spec<true>(cx, cy, cz, true, false, d, u0, u1, u2);
+                                                    else if (K < 0) dcsg_stencil_spec<true>(cx, cy, cz, true, false, d, u0, u1, u2);
 #endif
-            else dcsg_stencil<(K <= 0 ? 4 : K)>(s, cx, cy, cz, true, false, d, u0, u1, u2);
-            if (dcsg_node_culled(d, hdx, hdy, hdz)) continue;
-        }
-        if (threadIdx.x == 0) node_mask[slot] = 1;
-        swept_here++;
-        dcsg_node_axes(L, i0, g.side, tab);
-        const size_t base = ((size_t)i0[2] * n1 + (size_t)i0[1]) * n1 + (size_t)i0[0];
+                                                    else dcsg_stencil<(K <= 0 ? 4 : K)>(s, cx, cy, cz, true, false, d, u0, u1, u2);
+                                                    return d;
+                                                });
+        if (G.mask == 0u) continue;
+        swept_here += (unsigned int)__popc(G.mask);
+        const unsigned int total = (unsigned int)__popc(G.mask) * g.pts;
+        unsigned int t0 = 0u;
 #ifdef DCSG_HAVE_SPEC
         if (K < 0 && sdf_out && !nrm_out && dcsg_spec_threaded()) {
-            // threaded per-scene code, SDF only: four of the node's points per lane through ONE chain of calls (dcsg_spec_eval4)
-            for (unsigned int p0 = 0; p0 < g.pts; p0 += 4u * DCSG_BLOCK) {
+            // threaded per-scene code, SDF only: four points per lane through ONE chain of calls (dcsg_spec_eval4), while at
+            // least three of a pass's four quarters have work
+            for (; t0 + 3u * DCSG_BLOCK <= total; t0 += 4u * DCSG_BLOCK) {
                 dcsg_cl_float4 vx, vy, vz;
                 size_t at[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const unsigned int p = p0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x;
-                    const unsigned int cp = p < g.pts ? p : g.pts - 1u;  // idle lanes evaluate the last point and store nothing
-                    unsigned int lx, ly, lz;
-                    dcsg_node_local(g, cp, lx, ly, lz);
-                    vx[j] = tab[lx], vy[j] = tab[DCSG_NODE_TAB + ly], vz[j] = tab[2 * DCSG_NODE_TAB + lz];
-                    at[j] = base + ((size_t)lz * n1 + ly) * n1 + lx;
+                    const unsigned int t = t0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x;
+                    float x, y, z;
+                    dcsg_node_group_point(L, g, G, m_pts, t < total ? t : total - 1u, x, y, z, at[j]);  // idle lanes: the last point, nothing stored
+                    vx[j] = x, vy[j] = y, vz[j] = z;
                 }
                 const dcsg_cl_float4 o = dcsg_spec_eval4(vx, vy, vz);
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (p0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x < g.pts) sdf_out[at[j]] = o[j];
+                    if (t0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x < total) sdf_out[at[j]] = o[j];
             }
-            continue;
         }
 #endif
-        for (unsigned int p = threadIdx.x; p < g.pts; p += DCSG_BLOCK) {
-            unsigned int lx, ly, lz;
-            dcsg_node_local(g, p, lx, ly, lz);
-            float x = tab[lx], y = tab[DCSG_NODE_TAB + ly], z = tab[2 * DCSG_NODE_TAB + lz];
+        for (; t0 < total; t0 += DCSG_BLOCK) {
+            const unsigned int t = t0 + threadIdx.x;
+            float x, y, z;
+            size_t idx;
+            dcsg_node_group_point(L, g, G, m_pts, t < total ? t : total - 1u, x, y, z, idx);
             float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
             if (K == 0) {
                 if (sdf_out) sd = dcsg_primary_sdf(s, x, y, z);
@@ -1644,13 +1674,14 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
             } else {
                 dcsg_stencil<(K <= 0 ? 4 : K)>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz);
             }
-            size_t idx = base + ((size_t)lz * n1 + ly) * n1 + lx;
-            if (sdf_out) sdf_out[idx] = sd;
-            if (nrm_out) {
-                float* o = nrm_out + idx * 3;
-                o[0] = nx;
-                o[1] = ny;
-                o[2] = nz;
+            if (t < total) {
+                if (sdf_out) sdf_out[idx] = sd;
+                if (nrm_out) {
+                    float* o = nrm_out + idx * 3;
+                    o[0] = nx;
+                    o[1] = ny;
+                    o[2] = nz;
+                }
             }
         }
     }
@@ -1662,11 +1693,11 @@ __device__ __forceinline__ void dcsg_sweep_nodes_body(const uint4* __restrict__ 
     NAME(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,                 \
          unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,       \
          unsigned char* __restrict__ node_mask, float hdx, float hdy, float hdz, int z_own_lo, int z_own_hi,        \
-         unsigned int* __restrict__ n_swept, int /*group: the culling kernel's*/,                                   \
+         unsigned int* __restrict__ n_swept, int group,                                                             \
          const unsigned short* __restrict__ pattern, unsigned int n_pattern)                                         \
     {                                                                                                                \
         dcsg_sweep_nodes_body<K>(blob, n_vec4, L, nodes, n_nodes, shift, level, sdf_out, nrm_out, node_mask, hdx,    \
-                                 hdy, hdz, z_own_lo, z_own_hi, n_swept, pattern, n_pattern);                         \
+                                 hdy, hdz, z_own_lo, z_own_hi, n_swept, group, pattern, n_pattern);                  \
     }
 #ifdef DCSG_PART_EXPORT
 #ifndef DCSG_SET_SPEC  // the lean module of a specialised scene holds the _sp kernels only (csrc/jit.cpp)
@@ -2817,11 +2848,12 @@ dcsg_bbox_c4(const uint4* __restrict__ blob, int n_vec4, float cd, float half_ne
     dcsg_bbox_commit(mn, mx, cnt, result, zh);
 }
 
-// Node-wise sweep with tile culling.  The tile is the box of `group` consecutive nodes of the list: 8 = the children of one
+// Node-wise sweep with tile culling.  The tile is the box of `tile` consecutive nodes of the list: 8 = the children of one
 // parent (the mesher emits them together, and the 64 roots come in eights too), so that the scene's items are bounded
 // once per eight nodes -- the list of a box twice as wide is hardly longer where objects are many times the size of a node,
 // and bounding 256 items cost more than evaluating the three that were left (flat256 1024^3: 191 000 nodes, 1.85 ms); 1 =
-// a list per node (scenes with smooth joins, where every extra entry is dear).
+// a list per node (scenes with smooth joins, where every extra entry is dear).  The nodes' points are walked as in
+// dcsg_sweep_nodes_body (dcsg_node_group).
 extern "C" __global__ void __launch_bounds__(DCSG_BLOCK, DCSG_C4_WAVES)
 dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, const float* __restrict__ nodes,
                     unsigned int n_nodes, int shift, int level, float* __restrict__ sdf_out, float* __restrict__ nrm_out,
@@ -2830,10 +2862,9 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
                     unsigned int n_pattern)
 {
     SceneLds s = dcsg_stage_scene(blob, n_vec4);
-    __shared__ float tab[3 * DCSG_NODE_TAB];
     const DcsgNodeGrid g = dcsg_node_grid(shift, pattern, n_pattern);
-    const unsigned int side = g.side, pts = g.pts;
-    const size_t n1 = (size_t)L.res + 1u;
+    const unsigned int side = g.side;
+    const unsigned int m_pts = 0xffffffffu / g.pts + 1u;
     const float pad = nrm_out ? (float)K2_NORMAL_EPSILON * 1.01f : 0.0f;
     const unsigned int per = (unsigned int)group, n_groups = (n_nodes + per - 1u) / per;
     unsigned int swept_here = 0u;  // block-uniform; one atomic per block at the end
@@ -2864,56 +2895,44 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
         float R = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-6f;
         const unsigned short* list;
         int n_list = dcsg_build_block_list(s, n_vec4, 0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2]), R, list);
-      for (unsigned int n = n_first; n < n_end; n++) {
-        int i0[3], ic[3];
-        size_t slot;
-        dcsg_node_origin(L, nodes, n, shift, level, i0, ic, slot);
-        if (dcsg_node_outside_slab(i0[2], shift, z_own_lo, z_own_hi)) continue;  // block-uniform
-        {   // cull rule on the snapped centre (inside the node's box, so the group's list serves it); uniform
-            float d, u0, u1, u2;
-            dcsg_stencil<4>(s, dcsg_lattice_coord(L, 0, ic[0]), dcsg_lattice_coord(L, 1, ic[1]), dcsg_lattice_coord(L, 2, ic[2]),
-                            true, false, d, u0, u1, u2, list, n_list);
-            if (dcsg_node_culled(d, hdx, hdy, hdz)) continue;
-        }
-        if (threadIdx.x == 0) node_mask[slot] = 1;
-        swept_here++;
-        dcsg_node_axes(L, i0, side, tab);
-        const size_t base = ((size_t)i0[2] * n1 + (size_t)i0[1]) * n1 + (size_t)i0[0];
+        // cull rule on the snapped centres (inside the nodes' boxes, so the group's list serves them)
+        const DcsgNodeGroup G = dcsg_node_group(L, nodes, n_first, n_end, shift, level, hdx, hdy, hdz, z_own_lo, z_own_hi, node_mask,
+                                                [&](float cx, float cy, float cz) {
+                                                    float d, u0, u1, u2;
+                                                    dcsg_stencil<4>(s, cx, cy, cz, true, false, d, u0, u1, u2, list, n_list);
+                                                    return d;
+                                                });
+        if (G.mask == 0u) continue;
+        swept_here += (unsigned int)__popc(G.mask);
+        const unsigned int total = (unsigned int)__popc(G.mask) * g.pts;
+        unsigned int t0 = 0u;
         if (!nrm_out && sdf_out) {
-            // SDF only (what an export sweeps): a lane carries FOUR of the node's points through one interpretation of the
-            // list -- the entry decode (LDS record, readfirstlane, brush branch: a chain of dependent LDS reads and scalar
-            // moves per entry) is paid per 1 024 points instead of per 256, and four independent evaluations overlap.
-            // Same arithmetic per point: same bits.
-            for (unsigned int p0 = 0; p0 < pts; p0 += 4u * DCSG_BLOCK) {
+            // SDF only (what an export sweeps): a lane carries FOUR points through one interpretation of the list -- the entry
+            // decode (LDS record, readfirstlane, brush branch: a chain of dependent LDS reads and scalar moves per entry) is
+            // paid per 1 024 points instead of per 256, and four independent evaluations overlap -- while at least three of a
+            // pass's four quarters have work.  Same arithmetic per point: same bits.
+            for (; t0 + 3u * DCSG_BLOCK <= total; t0 += 4u * DCSG_BLOCK) {
                 float px[4], py[4], pz[4], o[4];
                 size_t at[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const unsigned int p = p0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x;
-                    const unsigned int cp = p < pts ? p : pts - 1u;  // idle lanes evaluate the last point and store nothing
-                    unsigned int lx, ly, lz;
-                    dcsg_node_local(g, cp, lx, ly, lz);
-                    px[j] = tab[lx], py[j] = tab[DCSG_NODE_TAB + ly], pz[j] = tab[2 * DCSG_NODE_TAB + lz];
-                    at[j] = base + ((size_t)lz * n1 + ly) * n1 + lx;
+                    const unsigned int t = t0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x;
+                    dcsg_node_group_point(L, g, G, m_pts, t < total ? t : total - 1u, px[j], py[j], pz[j], at[j]);  // idle lanes: the last point
                 }
                 dcsg_interp<4, 4>(s, px, py, pz, o, list, n_list);
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (p0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x < pts) sdf_out[at[j]] = o[j];
+                    if (t0 + (unsigned int)j * DCSG_BLOCK + threadIdx.x < total) sdf_out[at[j]] = o[j];
             }
-            continue;
         }
-        for (unsigned int p0 = 0; p0 < pts; p0 += DCSG_BLOCK) {
-            unsigned int p = p0 + threadIdx.x;
-            bool valid = p < pts;
-            unsigned int cp = valid ? p : pts - 1u;  // idle lanes evaluate the last point and store nothing
-            unsigned int lx, ly, lz;
-            dcsg_node_local(g, cp, lx, ly, lz);
-            float x = tab[lx], y = tab[DCSG_NODE_TAB + ly], z = tab[2 * DCSG_NODE_TAB + lz];
+        for (; t0 < total; t0 += DCSG_BLOCK) {
+            const unsigned int t = t0 + threadIdx.x;
+            float x, y, z;
+            size_t idx;
+            dcsg_node_group_point(L, g, G, m_pts, t < total ? t : total - 1u, x, y, z, idx);
             float sd = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
             dcsg_stencil<4>(s, x, y, z, sdf_out != nullptr, nrm_out != nullptr, sd, nx, ny, nz, list, n_list);
-            if (valid) {
-                size_t idx = base + ((size_t)lz * n1 + ly) * n1 + lx;
+            if (t < total) {
                 if (sdf_out) sdf_out[idx] = sd;
                 if (nrm_out) {
                     float* o = nrm_out + idx * 3;
@@ -2923,7 +2942,6 @@ dcsg_sweep_nodes_c4(const uint4* __restrict__ blob, int n_vec4, DcsgLattice L, c
                 }
             }
         }
-      }  // nodes of the group
     }
     if (threadIdx.x == 0 && swept_here) atomicAdd(n_swept, swept_here);
 }
