@@ -1496,7 +1496,8 @@ DCSG_SWEEP_KERNELS(dcsg_sweep_sp, -1)
 // Node-wise sweep (dcsg_export): the lattice values of the octree nodes of one level -- the nodes that reached the
 // mesher at the first level where the cull rule can drop a node for good -- instead of the whole lattice.  This is
 // the reference's lazy block cache (ISV.hpp:15-60) turned into one launch: a node of level m covers (2^(g-m)+1)^3
-// lattice points; one block per node, points shared with a neighbour are written by both (same bits).  The node's
+// lattice points, of which the sweep writes those the mesher can read (dcsg_in_sweep_pattern); blocks take the node list
+// eight siblings at a time (dcsg_node_group); points shared with a neighbour are written by both (same bits).  The node's
 // index on the level's grid comes from its snapped centre; node_mask records it for dcsg_lattice_point_written.
 // ---------------------------------------------------------------------------
 // i0: first lattice index of node n per axis; ic: the lattice point its centre snaps to (what the mesher's cull test
