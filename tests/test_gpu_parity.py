@@ -559,6 +559,26 @@ def test_projection_without_lattice(ev, oracle):
     assert np.array_equal(bits(t.cpu().numpy()), bits(want.reshape(-1, 3)))
 
 
+@pytest.mark.parametrize("levels", [(2, 4, 6), (3, 5, 6), (4, 4, 6), (4, 5, 7), (5, 6, 6), (3, 6, 7), (2, 2, 5), (4, 7, 7), (1, 5, 6)])
+def test_node_wise_pattern_over_level_configurations(ev, levels):
+    """The node-wise sweep writes only the points of a node that the mesher can read, a rule in the three levels of the export
+    configuration (kernels.hip, dcsg_in_sweep_pattern): corners and centres down to the maximum level (steps of 1, 2, 4 between
+    them), edge-test samples only when some level makes that test (maximum > sweep level), nodes of 3^3 ... 17^3 points.  For
+    every shape of the rule the mesh and the level statistics equal those of a dense sweep, where the rule does not exist."""
+    for name in ("design1", "flat256", "smooth256"):
+        load(ev, name)
+        cfg_txt = export_config_text(name, levels=levels, gd=2)
+        a = ev.export(cfg_txt)
+        ta = sorted_tris(ev.download_triangles())
+        b = ev.export(cfg_txt, dense_sweep=True)
+        tb = sorted_tris(ev.download_triangles())
+        assert a.triangles == b.triangles and np.array_equal(ta, tb), (name, levels)
+        for f in ("culled", "subdivided", "leaves", "triangles"):
+            assert list(getattr(a.mesh, f)) == list(getattr(b.mesh, f)), (name, levels, f)
+        if levels[2] - max(levels[0], 2) <= 4:
+            assert a.swept_nodes > 0 and b.swept_nodes == 0
+
+
 @pytest.mark.parametrize("name", ["design2", "flat256", "smooth256"])
 def test_export_switches_change_nothing(ev, name, monkeypatch, tmp_path):
     """The round-4 restructurings of the export keep a switch each for measurements.  Every one of them must leave the mesh,
