@@ -1950,6 +1950,14 @@ bool finish_file(int fd, off_t size, bool ok)
     return close(fd) == 0 && ok;
 }
 
+// what a formatting thread formats before it writes it: small enough to still be in its cache when the kernel copies it
+size_t writer_buffer_bytes()
+{
+    const char* e = getenv("DCSG_WRITER_BUFFER_KB");
+    long kb = e ? atol(e) : 1280;
+    return (size_t)(kb < 16 ? 16 : (kb > 65536 ? 65536 : kb)) << 10;
+}
+
 unsigned writer_threads()
 {
     const char* e = getenv("DCSG_WRITER_THREADS");
@@ -1991,7 +1999,7 @@ inline void stl_record(unsigned char* o, const float* v)
 bool stl_payload(int fd, const float* tris, uint64_t n, uint64_t first)
 {
     return parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
-        const uint64_t step = 1u << 15;  // triangles per buffer (1.6 MB)
+        const uint64_t step = writer_buffer_bytes() / 50;  // triangles per buffer
         std::vector<unsigned char> buf((size_t)step * 50);
         for (uint64_t a = t0; a < t1; a += step) {
             uint64_t b = a + step < t1 ? a + step : t1;
@@ -2010,7 +2018,7 @@ bool ply_faces(int fd, uint64_t n, uint64_t first, uint64_t total)
     char header[512];
     const off_t faces_at = ply_header(header, sizeof(header), total) + (off_t)(total * 72);
     return parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
-        const uint64_t step = 1u << 16;  // triangles per buffer (0.85 MB)
+        const uint64_t step = writer_buffer_bytes() / 13;  // triangles per buffer
         std::vector<unsigned char> fbuf((size_t)step * 13);
         for (uint64_t a = t0; a < t1; a += step) {
             uint64_t b = a + step < t1 ? a + step : t1;
@@ -2032,7 +2040,7 @@ bool ply_vertices(int fd, const float* tris, uint64_t n, uint64_t first, uint64_
     char header[512];
     const off_t verts_at = ply_header(header, sizeof(header), total);
     return parallel_ranges(n, writer_threads(), [=](uint64_t t0, uint64_t t1) {
-        const uint64_t step = 1u << 14;  // triangles per buffer (1.2 MB)
+        const uint64_t step = writer_buffer_bytes() / 72;  // triangles per buffer
         std::vector<unsigned char> vbuf((size_t)step * 72);
         for (uint64_t a = t0; a < t1; a += step) {
             uint64_t b = a + step < t1 ? a + step : t1;
